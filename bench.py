@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark of the multigrid V-cycle hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size M]
+
+One "step" is one V(2,2) cycle (omega 0.6, coarsest 2) of the 2D Poisson solver
+on an M x M fp64 grid, synthetic random right-hand side generated on the GPU,
+zero initial guess, everything resident in HBM before the timed region.  The
+metric is fine-grid DOF/s per V-cycle = M^2 * K / seconds.  For N > 1 the same
+M x M problem is split into j-slabs (strong scaling) and the script is launched
+once per GPU by torch.distributed.run.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the kernel with the largest
+share of the timed region (HIP events around every fine-level launch, on the
+stream the kernels run on); `cpu_baseline` is the CPU oracle (a plain-C port of
+the reference algorithm, 1 thread) timed on this box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+# Algorithmic (compulsory) HBM bytes per fine-level point and launch:
+# fp64 streams with perfect neighbour reuse.
+#   Jacobi sweep      : read u, f; write u'                     = 24
+#   residual          : read u, f; write r                      = 24
+#   restriction       : read r; write 1/4 coarse point          = 10
+#   prolong + correct : read 1/4 coarse point; read + write u   = 18
+#   residual norm     : read u, f                               = 16
+#   fused down  (nu1 sweeps + residual + restriction)           = 24*nu1 + 18
+#   fused up    (prolong + correct + nu2 sweeps)                = 18 + 24*nu2
+def algorithmic_bytes_per_point(kernel, nd, nu):
+    return {
+        "k_jacobi": 24.0,
+        "k_residual": 24.0,
+        "k_restrict": 10.0,
+        "k_refine<1>": 18.0,
+        "k_residual_norm": 16.0,
+        "k_fused_down": 24.0 * nd + 18.0,
+        "k_fused_up": 18.0 + 24.0 * nu,
+    }[kernel]
+
+
+def cycle_bytes(M, depth, nd, nu):
+    """B = sum_{l<depth} n_l*(24(nd+nu)+36) + 16*n_0, the per-cycle algorithmic traffic."""
+    tot = 0.0
+    m = M
+    for _ in range(depth):
+        tot += float(m) * m * (24.0 * (nd + nu) + 36.0)
+        m = (m - 1) // 2 + 1
+    return tot + 16.0 * M * M
+
+
+def cpu_baseline(M, nd, nu, omega, budget_note):
+    """Time the CPU oracle on one V-cycle of the same workload (1 thread)."""
+    import numpy as np
+    from oracle import oracle as O
+    from multigrid_amd import rhs
+    O.lib()
+    f = rhs.random_np(M)
+    v = np.zeros((M, M), order="F")
+    t0 = time.perf_counter()
+    O.multigrid(f, v, 1.0 / (M - 1), 1, nd, nu, omega, 2)
+    dt = time.perf_counter() - t0
+    return {"value": M * M / dt, "unit": "DOF/s", "cores": 1, "kind": "port",
+            "sample": "1 V(%d,%d) cycle at %dx%d incl. the two residual-norm passes, %.1f s%s"
+                      % (nd, nu, M, M, dt, budget_note)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=16385, help="grid points per side (2^k+1)")
+    ap.add_argument("--nd", type=int, default=2)
+    ap.add_argument("--nu", type=int, default=2)
+    ap.add_argument("--omega", type=float, default=0.6)
+    ap.add_argument("--schedule", type=int, default=0, help="0 default, 1 stepwise, 2 fused")
+    ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
+    ap.add_argument("--cpu-size", type=int, default=0, help="grid size for the CPU baseline (0 = --size)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import multigrid_amd as mg
+    from multigrid_amd import rhs
+
+    M, K, W = args.size, args.steps, args.warmup
+    dx = 1.0 / (M - 1)
+
+    if world == 1:
+        plan = mg.Plan(M, dx, 2, schedule=args.schedule)
+        plan.set(rhs.random_torch(M), mg.colmajor(M, M))
+        solver = plan
+        depth = plan.depth
+        schedule_name = "single-gpu"
+    else:
+        from multigrid_amd import slab
+        solver = slab.SlabSolver(M, dx, 2, schedule=args.schedule)
+        solver.set_random_rhs()
+        depth = solver.depth
+        schedule_name = "j-slabs x%d" % world
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if W > 0:
+        solver.cycles(W, args.nd, args.nu, args.omega)
+    solver.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    out = solver.cycles(K, args.nd, args.nu, args.omega)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = solver.profile_totals()
+    solver.profile(False)
+
+    if rank == 0:
+        n0 = float(M) * M
+        value = n0 * K / elapsed
+        B = cycle_bytes(M, depth, args.nd, args.nu)
+        roof = None
+        if prof:
+            kname, (cnt, tot_ms) = max(prof.items(), key=lambda kv: kv[1][1])
+            avg_s = tot_ms * 1e-3 / cnt
+            # on N GPUs each launch covers this rank's slab: n0 / world points
+            pts = n0 / world
+            bpp = algorithmic_bytes_per_point(kname, args.nd, args.nu)
+            achieved = bpp * pts / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "launches": cnt, "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_point": bpp,
+                    "points_per_launch": pts,
+                    "share_of_timed_region": tot_ms * 1e-3 / elapsed,
+                    "all_fine_level_kernels_ms": {k: [c, round(ms, 4)] for k, (c, ms) in prof.items()}}
+        line = {
+            "metric": "fine-grid DOF/s per V-cycle (fp64)",
+            "value": value, "unit": "DOF/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2D Poisson 5-point %dx%d fp64 V(%d,%d), omega %.2f, coarsest 2, random RHS, "
+                                   "zero guess, %d levels" % (M, M, args.nd, args.nu, args.omega, depth + 1),
+                       "M": M, "decomposition": schedule_name, "schedule": args.schedule},
+            "cycle_algorithmic_GB": B / 1e9,
+            "cycle_algorithmic_GBps": B * K / elapsed / 1e9,
+            "cycle_frac_of_hbm_peak": B * K / elapsed / 1e9 / (HBM_PEAK_GBS * world),
+            "resnorm_first_last": [float(out.ResidualNorms[0]), float(out.ResidualNorms[-1])],
+            "roofline": roof,
+        }
+        if world == 1 and args.cpu_baseline == "auto":
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega, "")
+            except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "DOF/s", "cores": 1, "kind": "port",
+                                        "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,186 @@
+/*
+ * mgx.h -- C ABI of libmgx, the MI355X (gfx950) implementation of the 2D
+ * Poisson geometric-multigrid V-cycle of RoyJames/MultiGrid (main.cpp).
+ *
+ * Conventions (all entry points)
+ *   - Arrays are fp64, COLUMN-MAJOR with leading dimension m, exactly the
+ *     storage DTMutableDoubleArray::Pointer() exposes
+ *     (reference DTSource/DTDoubleArray.h:38-49,125-128,184): A(i,j) = a[i + j*m].
+ *   - Grids are square and odd-sized (reference main.cpp:408-417); h = dx
+ *     (dy is carried by the reference but never used, main.cpp:180,263).
+ *   - Return value 0 = success, negative = MGX_ERR_*; mgx_last_error() gives
+ *     the message of the calling thread's last failure.  The library never
+ *     calls exit() and never prints unless options.verbose is set.
+ *   - "dev" pointers are HIP device pointers on the current device; "host"
+ *     pointers are ordinary host memory.  No torch types cross this boundary.
+ *   - Arithmetic is strict IEEE fp64 in the reference's left-to-right
+ *     evaluation order with no FMA contraction, so results are bit-identical
+ *     to the reference built without fast-math.
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_VERSION 100
+
+#define MGX_OK 0
+#define MGX_ERR_ARG (-1)      /* bad size / null pointer / non-square / even size   */
+#define MGX_ERR_HIERARCHY (-2) /* depth < 0 or an even-sized coarse level           */
+#define MGX_ERR_HIP (-3)      /* a HIP runtime call failed                           */
+#define MGX_ERR_NOMEM (-4)
+#define MGX_ERR_STATE (-5)    /* plan used before data was set, etc.                 */
+
+/* Solver options.  Zero-initialise, set struct_size = sizeof(mgx_options),
+ * then change what you need; NULL means all defaults. */
+typedef struct mgx_options {
+    int struct_size;
+    int device;       /* HIP device ordinal, -1 = current device (default)                     */
+    void *stream;     /* hipStream_t to run on, NULL = the null stream                          */
+    int schedule;     /* 0 = default (fused), 1 = one kernel per reference operator (stepwise),
+                         2 = fused streaming kernels                                            */
+    int verbose;      /* 1 = print the reference's "Direct solver not defined" message etc.     */
+    int reserved[8];
+} mgx_options;
+
+#define MGX_SCHEDULE_DEFAULT 0
+#define MGX_SCHEDULE_STEPWISE 1
+#define MGX_SCHEDULE_FUSED 2
+
+int mgx_version(void);
+const char *mgx_last_error(void);
+
+/* Number of coarsenings the reference performs for an m x m fine grid:
+ * int(log2(1.0f*(m-1)/coarsest) + 0.5f) in float arithmetic
+ * (reference main.cpp:286).  Level d has (m_{d-1}-1)/2+1 points per side
+ * (main.cpp:293). */
+int mgx_depth(int m, int coarsest);
+
+/* ------------------------------------------------------------------------
+ * Whole-solver entry point: replaces
+ *   MGOutputs MultiGrid(gridtype &prob, int Nv, int Ndown, int Nup,
+ *                       double omega, int coarsest, bool pureJacobi)
+ * (reference main.cpp:283-357, called at main.cpp:445).
+ *   f        host, m*n : right-hand side  (prob.f.DoubleData().Pointer())
+ *   v        host, m*n : initial guess with the Dirichlet values already on
+ *                        the boundary; overwritten with the solution in place,
+ *                        as the reference does through shared storage
+ *                        (main.cpp:288, DTSource/DTMesh2D.cpp:553-559)
+ *   dx                 : prob.v.Grid().dx()
+ *   resnorms host, Nv+1: infinity norm of the fine residual before the first
+ *                        cycle and after each cycle (main.cpp:307,351-353)
+ *   times    host, Nv+1: times[0]=0; times[k] = cumulative seconds of device
+ *                        time spent in cycles 1..k.  (The reference sums
+ *                        wall time around relax() only, main.cpp:320-322,
+ *                        342-344,350; with fused kernels smoothing is not
+ *                        separable, so whole-cycle device time is reported.)
+ * Stopping rule: exactly Nv cycles, no tolerance test (main.cpp:309).
+ * ------------------------------------------------------------------------ */
+int mgx_solve2d(const double *f, double *v, int m, int n, double dx,
+                int Nv, int Ndown, int Nup, double omega, int coarsest, int pure_jacobi,
+                double *resnorms, double *times, const mgx_options *opt);
+
+/* ------------------------------------------------------------------------
+ * Device-resident plan: the level hierarchy of MultiGrid() (main.cpp:286-300)
+ * allocated once in HBM, for callers that keep f and v on the GPU or run many
+ * solves of one size.  mgx_solve2d() is create + upload + cycles + download.
+ * ------------------------------------------------------------------------ */
+typedef struct mgx_plan mgx_plan;
+
+int mgx_plan_create(mgx_plan **plan, int m, double dx, int coarsest, const mgx_options *opt);
+int mgx_plan_destroy(mgx_plan *plan);
+int mgx_plan_depth(const mgx_plan *plan);
+int mgx_plan_level_m(const mgx_plan *plan, int level);
+size_t mgx_plan_bytes(const mgx_plan *plan); /* HBM held by the plan */
+
+/* Fine-level device buffers (m*m doubles each) the caller may fill directly,
+ * e.g. from a kernel of its own.  After writing v through this pointer call
+ * mgx_plan_commit() so the plan refreshes its second (ping-pong) copy of the
+ * boundary values. */
+double *mgx_plan_f_dev(mgx_plan *plan);
+double *mgx_plan_v_dev(mgx_plan *plan);
+int mgx_plan_commit(mgx_plan *plan);
+
+/* Device <-> plan copies on the plan's stream (asynchronous): f_dev / v_dev are
+ * the caller's own m*m device arrays; either may be NULL to leave that field
+ * as it is.  set_dev includes the commit. */
+int mgx_plan_set_dev(mgx_plan *plan, const double *f_dev, const double *v_dev);
+int mgx_plan_get_dev(mgx_plan *plan, double *v_dev);
+
+/* Host <-> plan copies (synchronous with respect to the plan's stream). */
+int mgx_plan_upload(mgx_plan *plan, const double *f_host, const double *v_host);
+int mgx_plan_download(mgx_plan *plan, double *v_host);
+
+/* Nv V(Ndown,Nup) cycles on the resident data; the V-cycle loop of
+ * main.cpp:309-354.  resnorms/times: host, Nv+1 entries, may be NULL.
+ * Coarse-level v is zero again after every cycle (main.cpp:345), so repeated calls
+ * continue from the current fine v exactly as one longer call would.  The
+ * per-cycle residual norm is always computed on the device, as the reference
+ * does; NULL only skips the copy to the host. */
+int mgx_plan_cycles(mgx_plan *plan, int Nv, int Ndown, int Nup, double omega, int pure_jacobi,
+                    double *resnorms, double *times);
+
+/* Per-launch timing of the FINE-LEVEL kernels, for roofline reporting: when
+ * enabled, every level-0 kernel launch inside mgx_plan_cycles() is bracketed by
+ * two HIP events on the plan's stream; the totals accumulate per kernel id
+ * until the next mgx_plan_profile() call.  No counterpart in the reference
+ * (which times relax() with gettimeofday, DTSource/DTTimer.h:13-19). */
+#define MGX_KERNEL_JACOBI 0
+#define MGX_KERNEL_RESIDUAL 1
+#define MGX_KERNEL_RESTRICT 2
+#define MGX_KERNEL_PROLONG_ADD 3
+#define MGX_KERNEL_RESNORM 4
+#define MGX_KERNEL_FUSED_DOWN 5
+#define MGX_KERNEL_FUSED_UP 6
+#define MGX_KERNEL_COUNT 7
+int mgx_plan_profile(mgx_plan *plan, int enable);
+int mgx_plan_profile_get(const mgx_plan *plan, int kernel_id, long *count, double *total_ms);
+const char *mgx_kernel_name(int kernel_id);
+
+/* ------------------------------------------------------------------------
+ * Per-operator entry points (device pointers, run on `stream`, asynchronous
+ * unless a host output is written).  They exist so that each kernel can be
+ * parity-tested against the reference operator it replaces.
+ * ------------------------------------------------------------------------ */
+
+/* relax(gridtype&, int Niter, double omega), main.cpp:171-199: Niter damped
+ * Jacobi sweeps on v (in/out), boundary untouched. */
+int mgx_relax(double *v_dev, const double *f_dev, int m, double dx, int niter, double omega, void *stream);
+
+/* residual(const gridtype&), main.cpp:255-281: r = f - Lap_h(v) on the
+ * interior, 0 on the boundary; r_dev receives all m*m entries. */
+int mgx_residual(const double *v_dev, const double *f_dev, double *r_dev, int m, double dx, void *stream);
+
+/* coarsen(fine, coarse), main.cpp:201-221, including the corner-term quirk at
+ * :218 (fine(2i+1,2j-1) twice, fine(2i-1,2j+1) never).  mc = (mf-1)/2+1. */
+int mgx_restrict(const double *fine_dev, int mf, double *coarse_dev, int mc, void *stream);
+
+/* refine(coarse, fine), main.cpp:223-253: bilinear interpolation, boundary 0;
+ * fine_dev receives all mf*mf entries. */
+int mgx_refine(const double *coarse_dev, int mc, double *fine_dev, int mf, void *stream);
+
+/* refine() followed by `cur += refined` (main.cpp:339-341 with
+ * DTSource/DTArrayTemplates.h:157-167) without the temporary. */
+int mgx_prolong_add(const double *coarse_dev, int mc, double *v_dev, int mf, void *stream);
+
+/* direct_solve(gridtype&), main.cpp:153-169.  Returns 1 (not an error) and
+ * leaves v unchanged when m != 3, as the reference does after printing. */
+int mgx_direct3x3(double *v_dev, const double *f_dev, int m, double dx, void *stream);
+
+/* calcNorm(array), main.cpp:147-150 = max(Maximum, -Minimum) with
+ * DTSource/DTDoubleArray.cpp:883-899,923-939 semantics (NaNs ignored).
+ * Synchronises the stream and writes the scalar to *out_host. */
+int mgx_norminf(const double *a_dev, size_t len, double *out_host, void *stream);
+
+/* calcNorm(residual(p)) without materialising the residual
+ * (main.cpp:307,351). */
+int mgx_residual_norm(const double *v_dev, const double *f_dev, int m, double dx, double *out_host, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of libmgx.so (the C ABI in include/mgx.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails the
+caller gets an exception.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmgx.so")
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+
+
+class MgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmgx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class mgx_options(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_int),
+        ("device", ctypes.c_int),
+        ("stream", ctypes.c_void_p),
+        ("schedule", ctypes.c_int),
+        ("verbose", ctypes.c_int),
+        ("reserved", ctypes.c_int * 8),
+    ]
+
+
+SCHEDULE_DEFAULT = 0
+SCHEDULE_STEPWISE = 1
+SCHEDULE_FUSED = 2
+
+# name -> (restype, argtypes); every symbol include/mgx.h declares.
+SIGNATURES = {
+    "mgx_version": (ctypes.c_int, []),
+    "mgx_last_error": (ctypes.c_char_p, []),
+    "mgx_depth": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "mgx_solve2d": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                   _vp, _vp, _vp]),
+    "mgx_plan_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_double, ctypes.c_int, _vp]),
+    "mgx_plan_destroy": (ctypes.c_int, [_vp]),
+    "mgx_plan_depth": (ctypes.c_int, [_vp]),
+    "mgx_plan_level_m": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mgx_plan_bytes": (ctypes.c_size_t, [_vp]),
+    "mgx_plan_f_dev": (_vp, [_vp]),
+    "mgx_plan_v_dev": (_vp, [_vp]),
+    "mgx_plan_commit": (ctypes.c_int, [_vp]),
+    "mgx_plan_profile": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mgx_plan_profile_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_long),
+                                            ctypes.POINTER(ctypes.c_double)]),
+    "mgx_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "mgx_plan_set_dev": (ctypes.c_int, [_vp, _vp, _vp]),
+    "mgx_plan_get_dev": (ctypes.c_int, [_vp, _vp]),
+    "mgx_plan_upload": (ctypes.c_int, [_vp, _vp, _vp]),
+    "mgx_plan_download": (ctypes.c_int, [_vp, _vp]),
+    "mgx_plan_cycles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                       ctypes.c_int, _vp, _vp]),
+    "mgx_relax": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double, _vp]),
+    "mgx_residual": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, _vp]),
+    "mgx_restrict": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    "mgx_refine": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    "mgx_prolong_add": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vp]),
+    "mgx_direct3x3": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp]),
+    "mgx_norminf": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp]),
+    "mgx_residual_norm": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
+}
+
+KERNEL_COUNT = 7
+
+_LIB = None
+
+
+def load():
+    """Load libmgx.so (built in-tree by `make -C multigrid_amd/csrc`)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("multigrid_amd: %s is missing; build it with `make -C multigrid_amd/csrc` "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    """Raise on a negative return code; pass non-negative codes through."""
+    if rc < 0:
+        msg = load().mgx_last_error()
+        raise MgxError(rc, msg.decode("utf-8", "replace") if msg else "")
+    return rc
+
+
+def make_options(device=-1, stream=None, schedule=SCHEDULE_DEFAULT, verbose=0):
+    o = mgx_options()
+    o.struct_size = ctypes.sizeof(mgx_options)
+    o.device = device
+    o.stream = stream
+    o.schedule = schedule
+    o.verbose = verbose
+    return o

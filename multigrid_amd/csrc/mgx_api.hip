@@ -1,0 +1,584 @@
+// mgx_api.hip -- the C ABI declared in include/mgx.h: argument checking, the
+// device-resident level hierarchy ("plan") and the V-cycle schedule of the
+// reference's MultiGrid() (main.cpp:283-357).  Kernels live in
+// mgx_kernels.hip (one per reference operator) and mgx_stream.hip (fused).
+#include "../../include/mgx.h"
+#include "mgx_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+using namespace mgx;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(MGX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+SweepCoef make_coef(double dx, double omega)
+{
+    SweepCoef c;
+    c.h2 = dx * dx;          // main.cpp:180
+    c.invh2 = 1.0 / c.h2;    // main.cpp:268
+    c.omega = omega;
+    c.nomega = 1 - omega;    // main.cpp:179
+    return c;
+}
+
+int check_grid(int m, const char *who)
+{
+    if (m < 3) return fail(MGX_ERR_ARG, "%s: grid size %d is below 3", who, m);
+    if ((m % 2) == 0) return fail(MGX_ERR_ARG, "%s: Input has even rows and columns! (m=%d)", who, m);
+    return MGX_OK;
+}
+
+struct Level {
+    int m = 0;
+    double dx = 0;
+    double *f = nullptr;
+    double *v[2] = {nullptr, nullptr};  // ping-pong pair; v[cur] is the live iterate
+    int cur = 0;
+    size_t n() const { return (size_t)m * (size_t)m; }
+};
+
+} // namespace
+
+struct mgx_plan {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int schedule = MGX_SCHEDULE_STEPWISE;
+    int verbose = 0;
+    int coarsest = 2;
+    int depth = 0;
+    std::vector<Level> lv;
+    double *r = nullptr;                 // residual scratch of the stepwise schedule (fine size)
+    unsigned long long *slots = nullptr; // encoded norms, one per cycle (+1)
+    int nslots = 0;
+    std::vector<hipEvent_t> events;
+    size_t bytes = 0;
+    // per-launch timing of the fine-level kernels (mgx_plan_profile)
+    int profile = 0;
+    struct ProfRec { int kid; hipEvent_t a, b; };
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> evpool;
+    size_t evused = 0;
+    double prof_ms[MGX_KERNEL_COUNT] = {0};
+    long prof_n[MGX_KERNEL_COUNT] = {0};
+};
+
+namespace {
+
+int plan_alloc(mgx_plan *p, void **ptr, size_t nbytes)
+{
+    HIP_TRY(hipMalloc(ptr, nbytes));
+    p->bytes += nbytes;
+    return MGX_OK;
+}
+
+int ensure_slots(mgx_plan *p, int n)
+{
+    if (n <= p->nslots) return MGX_OK;
+    if (p->slots) HIP_TRY(hipFree(p->slots));
+    p->slots = nullptr;
+    HIP_TRY(hipMalloc((void **)&p->slots, sizeof(unsigned long long) * (size_t)n));
+    p->nslots = n;
+    return MGX_OK;
+}
+
+int ensure_events(mgx_plan *p, int n)
+{
+    while ((int)p->events.size() < n) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        p->events.push_back(e);
+    }
+    return MGX_OK;
+}
+
+hipEvent_t prof_event(mgx_plan *p)
+{
+    if (p->evused == p->evpool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        p->evpool.push_back(e);
+    }
+    return p->evpool[p->evused++];
+}
+
+// Launch `call`; when profiling is on and the launch is on the fine level,
+// bracket it with two events on the plan's stream.
+#define LAUNCH(p, level, kid, call)                                              \
+    do {                                                                         \
+        const bool prof_ = (p)->profile && (level) == 0;                         \
+        hipEvent_t ea_ = nullptr, eb_ = nullptr;                                 \
+        if (prof_ && (ea_ = prof_event(p))) HIP_TRY(hipEventRecord(ea_, (p)->stream)); \
+        HIP_TRY(call);                                                           \
+        if (prof_ && ea_ && (eb_ = prof_event(p))) {                             \
+            HIP_TRY(hipEventRecord(eb_, (p)->stream));                           \
+            (p)->recs.push_back({(kid), ea_, eb_});                              \
+        }                                                                        \
+    } while (0)
+
+int prof_collect(mgx_plan *p)
+{
+    for (const mgx_plan::ProfRec &r : p->recs) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        p->prof_ms[r.kid] += (double)ms;
+        p->prof_n[r.kid] += 1;
+    }
+    p->recs.clear();
+    p->evused = 0;
+    return MGX_OK;
+}
+
+// niter Jacobi sweeps on one level, ping-ponging its two v buffers.
+int level_relax(mgx_plan *p, int d, int niter, double omega)
+{
+    Level &L = p->lv[d];
+    const SweepCoef c = make_coef(L.dx, omega);
+    for (int it = 0; it < niter; it++) {
+        LAUNCH(p, d, MGX_KERNEL_JACOBI, launch_jacobi(L.v[L.cur], L.v[L.cur ^ 1], L.f, L.m, 1, L.m - 1, c, p->stream));
+        L.cur ^= 1;
+    }
+    return MGX_OK;
+}
+
+// One V(Ndown,Nup) cycle, one kernel per reference operator:
+// the body of the loop at main.cpp:317-346.
+int vcycle_stepwise(mgx_plan *p, int Ndown, int Nup, double omega)
+{
+    const int depth = p->depth;
+    hipStream_t s = p->stream;
+    for (int d = 0; d < depth; d++) {  // main.cpp:317-328
+        Level &L = p->lv[d];
+        Level &C = p->lv[d + 1];
+        int rc = level_relax(p, d, Ndown, omega);
+        if (rc) return rc;
+        const SweepCoef c = make_coef(L.dx, omega);
+        // residual(): boundary columns 0 and m-1 are zero, the kernel fills the rest
+        HIP_TRY(hipMemsetAsync(p->r, 0, sizeof(double) * (size_t)L.m, s));
+        HIP_TRY(hipMemsetAsync(p->r + (size_t)(L.m - 1) * L.m, 0, sizeof(double) * (size_t)L.m, s));
+        LAUNCH(p, d, MGX_KERNEL_RESIDUAL, launch_residual(L.v[L.cur], L.f, p->r, L.m, 1, L.m - 1, c, s));
+        // coarsen(): interior of the coarse f; its boundary stays 0 from allocation
+        LAUNCH(p, d, MGX_KERNEL_RESTRICT, launch_restrict(p->r, L.m, C.f, C.m, 1, C.m - 1, 0, 0, s));
+    }
+    {  // main.cpp:331
+        Level &B = p->lv[depth];
+        if (B.m == 3) {
+            HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, s));
+        } else if (p->verbose) {
+            printf("Error: Direct solver not defined for %dx%d matrices!\n", B.m, B.m);
+        }
+    }
+    for (int d = depth - 1; d >= 0; d--) {  // main.cpp:335-346
+        Level &L = p->lv[d];
+        Level &C = p->lv[d + 1];
+        LAUNCH(p, d, MGX_KERNEL_PROLONG_ADD, launch_refine(C.v[C.cur], C.m, L.v[L.cur], L.m, 1, L.m - 1, 0, 0, 1, s));
+        int rc = level_relax(p, d, Nup, omega);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(C.v[C.cur], 0, sizeof(double) * C.n(), s));  // main.cpp:345
+    }
+    return MGX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mgx_version(void) { return MGX_VERSION; }
+
+const char *mgx_last_error(void) { return g_err; }
+
+int mgx_depth(int m, int coarsest)
+{
+    // main.cpp:286, float arithmetic on purpose.
+    const float ratio = 1.0f * (float)(m - 1) / (float)coarsest;
+    return (int)(log2f(ratio) + 0.5f);
+}
+
+int mgx_plan_create(mgx_plan **out, int m, double dx, int coarsest, const mgx_options *opt)
+{
+    if (!out) return fail(MGX_ERR_ARG, "mgx_plan_create: null output pointer");
+    *out = nullptr;
+    int rc = check_grid(m, "mgx_plan_create");
+    if (rc) return rc;
+    if (coarsest < 1) return fail(MGX_ERR_ARG, "mgx_plan_create: coarsest must be >= 1 (got %d)", coarsest);
+    if (!(dx > 0.0)) return fail(MGX_ERR_ARG, "mgx_plan_create: dx must be positive");
+    const int depth = mgx_depth(m, coarsest);
+    if (depth < 0) return fail(MGX_ERR_HIERARCHY, "mgx_plan_create: depth %d < 0 for m=%d coarsest=%d", depth, m, coarsest);
+    std::vector<int> dims(depth + 1);
+    dims[0] = m;
+    for (int d = 1; d <= depth; d++) {
+        dims[d] = (dims[d - 1] - 1) / 2 + 1;  // main.cpp:293
+        if (dims[d] < 3 || (dims[d] % 2) == 0)
+            return fail(MGX_ERR_HIERARCHY,
+                        "mgx_plan_create: level %d would be %dx%d (needs odd >= 3): the reference indexes out of "
+                        "range there", d, dims[d], dims[d]);
+    }
+
+    mgx_plan *p = new (std::nothrow) mgx_plan();
+    if (!p) return fail(MGX_ERR_NOMEM, "mgx_plan_create: out of host memory");
+    if (opt) {
+        if (opt->struct_size != (int)sizeof(mgx_options)) {
+            delete p;
+            return fail(MGX_ERR_ARG, "mgx_plan_create: options.struct_size %d != %d", opt->struct_size,
+                        (int)sizeof(mgx_options));
+        }
+        p->stream = (hipStream_t)opt->stream;
+        p->verbose = opt->verbose;
+        p->schedule = opt->schedule == MGX_SCHEDULE_DEFAULT ? MGX_SCHEDULE_STEPWISE : opt->schedule;
+        if (opt->device >= 0) {
+            hipError_t e = hipSetDevice(opt->device);
+            if (e != hipSuccess) {
+                delete p;
+                return fail(MGX_ERR_HIP, "hipSetDevice(%d): %s", opt->device, hipGetErrorString(e));
+            }
+        }
+    }
+    if (p->schedule != MGX_SCHEDULE_STEPWISE) {
+        delete p;
+        return fail(MGX_ERR_ARG, "mgx_plan_create: schedule %d is not available", opt ? opt->schedule : -1);
+    }
+    {
+        hipError_t e = hipGetDevice(&p->device);
+        if (e != hipSuccess) {
+            delete p;
+            return fail(MGX_ERR_HIP, "hipGetDevice: %s (is a GPU visible?)", hipGetErrorString(e));
+        }
+    }
+    p->coarsest = coarsest;
+    p->depth = depth;
+    p->lv.resize(depth + 1);
+    double h = dx;
+    for (int d = 0; d <= depth; d++) {
+        Level &L = p->lv[d];
+        L.m = dims[d];
+        L.dx = h;
+        h = h * 2.0;  // main.cpp:297
+        const size_t nb = sizeof(double) * L.n();
+        rc = plan_alloc(p, (void **)&L.f, nb);
+        if (!rc) rc = plan_alloc(p, (void **)&L.v[0], nb);
+        if (!rc) rc = plan_alloc(p, (void **)&L.v[1], nb);
+        if (rc) { mgx_plan_destroy(p); return rc; }
+        // main.cpp:295-299: every level starts as zeros
+        hipError_t e = hipMemsetAsync(L.f, 0, nb, p->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(L.v[0], 0, nb, p->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(L.v[1], 0, nb, p->stream);
+        if (e != hipSuccess) { mgx_plan_destroy(p); return fail(MGX_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    }
+    rc = plan_alloc(p, (void **)&p->r, sizeof(double) * p->lv[0].n());
+    if (rc) { mgx_plan_destroy(p); return rc; }
+    *out = p;
+    return MGX_OK;
+}
+
+int mgx_plan_destroy(mgx_plan *p)
+{
+    if (!p) return MGX_OK;
+    (void)hipStreamSynchronize(p->stream);
+    for (Level &L : p->lv) {
+        if (L.f) (void)hipFree(L.f);
+        if (L.v[0]) (void)hipFree(L.v[0]);
+        if (L.v[1]) (void)hipFree(L.v[1]);
+    }
+    if (p->r) (void)hipFree(p->r);
+    if (p->slots) (void)hipFree(p->slots);
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->evpool) (void)hipEventDestroy(e);
+    delete p;
+    return MGX_OK;
+}
+
+int mgx_plan_depth(const mgx_plan *p) { return p ? p->depth : MGX_ERR_ARG; }
+
+int mgx_plan_level_m(const mgx_plan *p, int level)
+{
+    if (!p || level < 0 || level > p->depth) return MGX_ERR_ARG;
+    return p->lv[level].m;
+}
+
+size_t mgx_plan_bytes(const mgx_plan *p) { return p ? p->bytes : 0; }
+
+double *mgx_plan_f_dev(mgx_plan *p) { return p ? p->lv[0].f : nullptr; }
+
+double *mgx_plan_v_dev(mgx_plan *p) { return p ? p->lv[0].v[0] : nullptr; }
+
+int mgx_plan_commit(mgx_plan *p)
+{
+    if (!p) return fail(MGX_ERR_ARG, "mgx_plan_commit: null plan");
+    Level &L = p->lv[0];
+    L.cur = 0;
+    // both ping-pong buffers must carry the same Dirichlet boundary values
+    HIP_TRY(hipMemcpyAsync(L.v[1], L.v[0], sizeof(double) * L.n(), hipMemcpyDeviceToDevice, p->stream));
+    return MGX_OK;
+}
+
+int mgx_plan_profile(mgx_plan *p, int enable)
+{
+    if (!p) return fail(MGX_ERR_ARG, "mgx_plan_profile: null plan");
+    p->profile = enable ? 1 : 0;
+    for (int k = 0; k < MGX_KERNEL_COUNT; k++) { p->prof_ms[k] = 0; p->prof_n[k] = 0; }
+    return MGX_OK;
+}
+
+int mgx_plan_profile_get(const mgx_plan *p, int kernel_id, long *count, double *total_ms)
+{
+    if (!p || kernel_id < 0 || kernel_id >= MGX_KERNEL_COUNT) return fail(MGX_ERR_ARG, "mgx_plan_profile_get: bad argument");
+    if (count) *count = p->prof_n[kernel_id];
+    if (total_ms) *total_ms = p->prof_ms[kernel_id];
+    return MGX_OK;
+}
+
+const char *mgx_kernel_name(int kernel_id)
+{
+    static const char *names[MGX_KERNEL_COUNT] = {"k_jacobi", "k_residual", "k_restrict", "k_refine<1>",
+                                                  "k_residual_norm", "k_fused_down", "k_fused_up"};
+    return (kernel_id >= 0 && kernel_id < MGX_KERNEL_COUNT) ? names[kernel_id] : "";
+}
+
+int mgx_plan_set_dev(mgx_plan *p, const double *f_dev, const double *v_dev)
+{
+    if (!p) return fail(MGX_ERR_ARG, "mgx_plan_set_dev: null plan");
+    Level &L = p->lv[0];
+    const size_t nb = sizeof(double) * L.n();
+    if (f_dev) HIP_TRY(hipMemcpyAsync(L.f, f_dev, nb, hipMemcpyDeviceToDevice, p->stream));
+    if (v_dev) HIP_TRY(hipMemcpyAsync(L.v[0], v_dev, nb, hipMemcpyDeviceToDevice, p->stream));
+    return mgx_plan_commit(p);
+}
+
+int mgx_plan_get_dev(mgx_plan *p, double *v_dev)
+{
+    if (!p || !v_dev) return fail(MGX_ERR_ARG, "mgx_plan_get_dev: null argument");
+    Level &L = p->lv[0];
+    HIP_TRY(hipMemcpyAsync(v_dev, L.v[0], sizeof(double) * L.n(), hipMemcpyDeviceToDevice, p->stream));
+    return MGX_OK;
+}
+
+int mgx_plan_upload(mgx_plan *p, const double *f_host, const double *v_host)
+{
+    if (!p) return fail(MGX_ERR_ARG, "mgx_plan_upload: null plan");
+    Level &L = p->lv[0];
+    const size_t nb = sizeof(double) * L.n();
+    if (f_host) HIP_TRY(hipMemcpyAsync(L.f, f_host, nb, hipMemcpyHostToDevice, p->stream));
+    if (v_host) HIP_TRY(hipMemcpyAsync(L.v[0], v_host, nb, hipMemcpyHostToDevice, p->stream));
+    int rc = mgx_plan_commit(p);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MGX_OK;
+}
+
+int mgx_plan_download(mgx_plan *p, double *v_host)
+{
+    if (!p || !v_host) return fail(MGX_ERR_ARG, "mgx_plan_download: null argument");
+    Level &L = p->lv[0];
+    HIP_TRY(hipMemcpyAsync(v_host, L.v[0], sizeof(double) * L.n(), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MGX_OK;
+}
+
+int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int pure_jacobi,
+                    double *resnorms, double *times)
+{
+    if (!p) return fail(MGX_ERR_ARG, "mgx_plan_cycles: null plan");
+    if (Nv < 0 || Ndown < 0 || Nup < 0) return fail(MGX_ERR_ARG, "mgx_plan_cycles: negative count");
+    hipStream_t s = p->stream;
+    int rc = ensure_slots(p, Nv + 1);
+    if (!rc) rc = ensure_events(p, Nv + 1);
+    if (rc) return rc;
+    Level &L0 = p->lv[0];
+    const SweepCoef c0 = make_coef(L0.dx, omega);
+    HIP_TRY(hipMemsetAsync(p->slots, 0, sizeof(unsigned long long) * (size_t)(Nv + 1), s));
+    // main.cpp:307
+    LAUNCH(p, 0, MGX_KERNEL_RESNORM, launch_residual_norm(L0.v[L0.cur], L0.f, L0.m, 1, L0.m - 1, c0, p->slots + 0, s));
+    HIP_TRY(hipEventRecord(p->events[0], s));
+    for (int iter = 0; iter < Nv; iter++) {  // main.cpp:309
+        if (!pure_jacobi) {
+            rc = vcycle_stepwise(p, Ndown, Nup, omega);
+        } else {
+            rc = level_relax(p, 0, 1, omega);  // main.cpp:348
+        }
+        if (rc) return rc;
+        // main.cpp:351-353
+        LAUNCH(p, 0, MGX_KERNEL_RESNORM, launch_residual_norm(L0.v[L0.cur], L0.f, L0.m, 1, L0.m - 1, c0, p->slots + iter + 1, s));
+        HIP_TRY(hipEventRecord(p->events[iter + 1], s));
+    }
+    if (L0.cur != 0) {  // leave the solution in the buffer mgx_plan_v_dev() exposes
+        HIP_TRY(hipMemcpyAsync(L0.v[0], L0.v[1], sizeof(double) * L0.n(), hipMemcpyDeviceToDevice, s));
+        L0.cur = 0;
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    rc = prof_collect(p);
+    if (rc) return rc;
+    if (resnorms) {
+        std::vector<unsigned long long> keys((size_t)Nv + 1);
+        HIP_TRY(hipMemcpy(keys.data(), p->slots, sizeof(unsigned long long) * keys.size(), hipMemcpyDeviceToHost));
+        for (int k = 0; k <= Nv; k++) resnorms[k] = norm_decode(keys[k]);
+    }
+    if (times) {
+        times[0] = 0;  // main.cpp:308
+        for (int k = 1; k <= Nv; k++) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, p->events[k - 1], p->events[k]));
+            times[k] = times[k - 1] + 1e-3 * (double)ms;  // main.cpp:350 (whole-cycle device time)
+        }
+    }
+    return MGX_OK;
+}
+
+int mgx_solve2d(const double *f, double *v, int m, int n, double dx,
+                int Nv, int Ndown, int Nup, double omega, int coarsest, int pure_jacobi,
+                double *resnorms, double *times, const mgx_options *opt)
+{
+    if (!f || !v) return fail(MGX_ERR_ARG, "mgx_solve2d: null f or v");
+    if (m != n) return fail(MGX_ERR_ARG, "mgx_solve2d: Input is not square matrix! (%dx%d)", m, n);  // main.cpp:408-412
+    mgx_plan *p = nullptr;
+    int rc = mgx_plan_create(&p, m, dx, coarsest, opt);
+    if (rc) return rc;
+    rc = mgx_plan_upload(p, f, v);
+    if (!rc) rc = mgx_plan_cycles(p, Nv, Ndown, Nup, omega, pure_jacobi, resnorms, times);
+    if (!rc) rc = mgx_plan_download(p, v);
+    mgx_plan_destroy(p);
+    return rc;
+}
+
+// ---- per-operator entry points ----------------------------------------------
+
+int mgx_relax(double *v, const double *f, int m, double dx, int niter, double omega, void *stream)
+{
+    if (!v || !f) return fail(MGX_ERR_ARG, "mgx_relax: null pointer");
+    int rc = check_grid(m, "mgx_relax");
+    if (rc) return rc;
+    if (niter <= 0) return MGX_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nb = sizeof(double) * (size_t)m * (size_t)m;
+    double *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, nb));
+    hipError_t e = hipMemcpyAsync(tmp, v, nb, hipMemcpyDeviceToDevice, s);  // boundary values into the pong buffer
+    const SweepCoef c = make_coef(dx, omega);
+    double *buf[2] = {v, tmp};
+    int cur = 0;
+    for (int it = 0; it < niter && e == hipSuccess; it++) {
+        e = launch_jacobi(buf[cur], buf[cur ^ 1], f, m, 1, m - 1, c, s);
+        cur ^= 1;
+    }
+    if (e == hipSuccess && cur == 1) e = hipMemcpyAsync(v, tmp, nb, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(MGX_ERR_HIP, "mgx_relax: %s", hipGetErrorString(e));
+    return MGX_OK;
+}
+
+int mgx_residual(const double *v, const double *f, double *r, int m, double dx, void *stream)
+{
+    if (!v || !f || !r) return fail(MGX_ERR_ARG, "mgx_residual: null pointer");
+    int rc = check_grid(m, "mgx_residual");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const SweepCoef c = make_coef(dx, 0.0);
+    HIP_TRY(hipMemsetAsync(r, 0, sizeof(double) * (size_t)m, s));
+    HIP_TRY(hipMemsetAsync(r + (size_t)(m - 1) * m, 0, sizeof(double) * (size_t)m, s));
+    HIP_TRY(launch_residual(v, f, r, m, 1, m - 1, c, s));
+    return MGX_OK;
+}
+
+int mgx_restrict(const double *fine, int mf, double *coarse, int mc, void *stream)
+{
+    if (!fine || !coarse) return fail(MGX_ERR_ARG, "mgx_restrict: null pointer");
+    int rc = check_grid(mf, "mgx_restrict");
+    if (rc) return rc;
+    if (mc != (mf - 1) / 2 + 1 || mc < 2) return fail(MGX_ERR_ARG, "mgx_restrict: mc=%d does not pair with mf=%d", mc, mf);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(coarse, 0, sizeof(double) * (size_t)mc * mc, s));  // main.cpp:211
+    HIP_TRY(launch_restrict(fine, mf, coarse, mc, 1, mc - 1, 0, 0, s));
+    return MGX_OK;
+}
+
+int mgx_refine(const double *coarse, int mc, double *fine, int mf, void *stream)
+{
+    if (!fine || !coarse) return fail(MGX_ERR_ARG, "mgx_refine: null pointer");
+    int rc = check_grid(mf, "mgx_refine");
+    if (rc) return rc;
+    if (mc != (mf - 1) / 2 + 1) return fail(MGX_ERR_ARG, "mgx_refine: mc=%d does not pair with mf=%d", mc, mf);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(fine, 0, sizeof(double) * (size_t)mf * mf, s));  // main.cpp:229
+    HIP_TRY(launch_refine(coarse, mc, fine, mf, 1, mf - 1, 0, 0, 0, s));
+    return MGX_OK;
+}
+
+int mgx_prolong_add(const double *coarse, int mc, double *v, int mf, void *stream)
+{
+    if (!v || !coarse) return fail(MGX_ERR_ARG, "mgx_prolong_add: null pointer");
+    int rc = check_grid(mf, "mgx_prolong_add");
+    if (rc) return rc;
+    if (mc != (mf - 1) / 2 + 1) return fail(MGX_ERR_ARG, "mgx_prolong_add: mc=%d does not pair with mf=%d", mc, mf);
+    HIP_TRY(launch_refine(coarse, mc, v, mf, 1, mf - 1, 0, 0, 1, (hipStream_t)stream));
+    return MGX_OK;
+}
+
+int mgx_direct3x3(double *v, const double *f, int m, double dx, void *stream)
+{
+    if (!v || !f) return fail(MGX_ERR_ARG, "mgx_direct3x3: null pointer");
+    if (m != 3) return 1;  // main.cpp:167: message, no change
+    HIP_TRY(launch_direct3x3(v, f, dx * dx, (hipStream_t)stream));
+    return MGX_OK;
+}
+
+static int read_slot(unsigned long long *slot, double *out, hipStream_t s)
+{
+    unsigned long long key = 0;
+    HIP_TRY(hipMemcpyAsync(&key, slot, sizeof(key), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *out = norm_decode(key);
+    return MGX_OK;
+}
+
+int mgx_norminf(const double *a, size_t len, double *out, void *stream)
+{
+    if ((!a && len) || !out) return fail(MGX_ERR_ARG, "mgx_norminf: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *slot = nullptr;
+    HIP_TRY(hipMalloc((void **)&slot, sizeof(*slot)));
+    hipError_t e = hipMemsetAsync(slot, 0, sizeof(*slot), s);
+    if (e == hipSuccess && len) e = launch_norminf(a, len, slot, s);
+    int rc = (e == hipSuccess) ? read_slot(slot, out, s) : fail(MGX_ERR_HIP, "mgx_norminf: %s", hipGetErrorString(e));
+    (void)hipFree(slot);
+    return rc;
+}
+
+int mgx_residual_norm(const double *v, const double *f, int m, double dx, double *out, void *stream)
+{
+    if (!v || !f || !out) return fail(MGX_ERR_ARG, "mgx_residual_norm: null pointer");
+    int rc = check_grid(m, "mgx_residual_norm");
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *slot = nullptr;
+    HIP_TRY(hipMalloc((void **)&slot, sizeof(*slot)));
+    hipError_t e = hipMemsetAsync(slot, 0, sizeof(*slot), s);
+    if (e == hipSuccess) e = launch_residual_norm(v, f, m, 1, m - 1, make_coef(dx, 0.0), slot, s);
+    rc = (e == hipSuccess) ? read_slot(slot, out, s) : fail(MGX_ERR_HIP, "mgx_residual_norm: %s", hipGetErrorString(e));
+    (void)hipFree(slot);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,282 @@
+// mgx_kernels.hip -- one gfx950 kernel per reference operator ("stepwise"
+// schedule).  These are the parity anchors: each kernel evaluates exactly the
+// expression tree of the reference operator it replaces, one grid point per
+// lane, lanes running along the contiguous index i so that every wavefront
+// load/store is a 512-byte coalesced segment of one column.
+//
+// Compile with -ffp-contract=off: a fused multiply-add anywhere in these
+// expressions changes the last bit and breaks parity.
+#include "mgx_internal.h"
+
+namespace mgx {
+
+static constexpr int BX = 64;  // lanes along i (one wavefront wide)
+static constexpr int BY = 4;   // columns per workgroup
+
+static inline dim3 grid2d(int rows, int cols)
+{
+    return dim3((unsigned)((rows + BX - 1) / BX), (unsigned)((cols + BY - 1) / BY), 1);
+}
+
+// ---------------------------------------------------------------------------
+// Damped Jacobi sweep, reference main.cpp:194-195:
+//   u_new = u_old*nomega + ((uW+uE+uS+uN - f*h2)*0.25)*omega
+// uin is the pre-sweep copy (main.cpp:186), uout the new iterate; the caller
+// ping-pongs the two buffers.  Only interior rows 1..m-2 of columns
+// [jlo,jhi) are written.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BX * BY) void k_jacobi(const double *__restrict__ uin, double *__restrict__ uout,
+                                                    const double *__restrict__ f, int m, int jlo, int jhi,
+                                                    SweepCoef c)
+{
+    const int i = 1 + blockIdx.x * BX + threadIdx.x;
+    const int j = jlo + blockIdx.y * BY + threadIdx.y;
+    if (i >= m - 1 || j >= jhi) return;
+    const size_t k = (size_t)i + (size_t)j * (size_t)m;
+    double s = uin[k - 1] + uin[k + 1];
+    s = s + uin[k - m];
+    s = s + uin[k + m];
+    s = s - f[k] * c.h2;
+    s = s * 0.25;
+    s = s * c.omega;
+    uout[k] = uin[k] * c.nomega + s;
+}
+
+hipError_t launch_jacobi(const double *uin, double *uout, const double *f, int m, int jlo, int jhi,
+                         const SweepCoef &c, hipStream_t s)
+{
+    if (m < 3 || jhi <= jlo) return hipSuccess;
+    hipLaunchKernelGGL(k_jacobi, grid2d(m - 2, jhi - jlo), dim3(BX, BY), 0, s, uin, uout, f, m, jlo, jhi, c);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Residual, reference main.cpp:277:
+//   r = f - (uW+uE+uS+uN - u*4.0) * invh2
+// Columns [jlo,jhi): rows 1..m-2 get the residual, rows 0 and m-1 get 0
+// (main.cpp:267).  Boundary COLUMNS are zeroed by the caller (memset).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double residual_at(const double *__restrict__ u, const double *__restrict__ f, size_t k,
+                                              int m, double invh2)
+{
+    double s = u[k - 1] + u[k + 1];
+    s = s + u[k - m];
+    s = s + u[k + m];
+    s = s - u[k] * 4.0;
+    s = s * invh2;
+    return f[k] - s;
+}
+
+__global__ __launch_bounds__(BX * BY) void k_residual(const double *__restrict__ u, const double *__restrict__ f,
+                                                      double *__restrict__ r, int m, int jlo, int jhi, SweepCoef c)
+{
+    const int i = blockIdx.x * BX + threadIdx.x;
+    const int j = jlo + blockIdx.y * BY + threadIdx.y;
+    if (i >= m || j >= jhi) return;
+    const size_t k = (size_t)i + (size_t)j * (size_t)m;
+    r[k] = (i == 0 || i == m - 1) ? 0.0 : residual_at(u, f, k, m, c.invh2);
+}
+
+hipError_t launch_residual(const double *u, const double *f, double *r, int m, int jlo, int jhi,
+                           const SweepCoef &c, hipStream_t s)
+{
+    if (m < 3 || jhi <= jlo) return hipSuccess;
+    hipLaunchKernelGGL(k_residual, grid2d(m, jhi - jlo), dim3(BX, BY), 0, s, u, f, r, m, jlo, jhi, c);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Restriction, reference main.cpp:216-218 (corner-term quirk kept: the fine
+// point (2I+1,2J-1) enters twice, (2I-1,2J+1) never):
+//   c = F(2I,2J)*1/4
+//     + (F(2I-1,2J)+F(2I+1,2J)+F(2I,2J-1)+F(2I,2J+1))*1/8
+//     + (F(2I-1,2J-1)+F(2I+1,2J-1)+F(2I+1,2J-1)+F(2I+1,2J+1))*1/16
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BX * BY) void k_restrict(const double *__restrict__ fine, int mf,
+                                                      double *__restrict__ coarse, int mc, int Jlo, int Jhi,
+                                                      int gf0, int gc0)
+{
+    const int I = 1 + blockIdx.x * BX + threadIdx.x;
+    const int J = Jlo + blockIdx.y * BY + threadIdx.y;
+    if (I >= mc - 1 || J >= Jhi) return;
+    const int jf = 2 * (J + gc0) - gf0;  // local fine column of this coarse column
+    const size_t kc = (size_t)(2 * I) + (size_t)jf * (size_t)mf;
+    const size_t m_ = (size_t)mf;
+    double a = fine[kc] * 0.25;
+    double nb = fine[kc - 1] + fine[kc + 1];
+    nb = nb + fine[kc - m_];
+    nb = nb + fine[kc + m_];
+    nb = nb * 0.125;
+    double cn = fine[kc - 1 - m_] + fine[kc + 1 - m_];
+    cn = cn + fine[kc + 1 - m_];
+    cn = cn + fine[kc + 1 + m_];
+    cn = cn * 0.0625;
+    coarse[(size_t)I + (size_t)J * (size_t)mc] = (a + nb) + cn;
+}
+
+hipError_t launch_restrict(const double *fine, int mf, double *coarse, int mc, int Jlo, int Jhi,
+                           int gf0, int gc0, hipStream_t s)
+{
+    if (mc < 3 || Jhi <= Jlo) return hipSuccess;
+    hipLaunchKernelGGL(k_restrict, grid2d(mc - 2, Jhi - Jlo), dim3(BX, BY), 0, s, fine, mf, coarse, mc, Jlo, Jhi,
+                       gf0, gc0);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Prolongation, reference main.cpp:234-246, optionally fused with the
+// whole-array `cur += refined` of main.cpp:341 (boundary entries of `refined`
+// are 0, and x + 0.0 == x bit for bit except -0.0 + 0.0 = +0.0, which the
+// caller's boundary handling reproduces; see launch_refine).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double prolong_at(const double *__restrict__ c, int mc, int i, int jg, int gc0)
+{
+    const int I = i >> 1;
+    const int J = (jg >> 1) - gc0;
+    const size_t k = (size_t)I + (size_t)J * (size_t)mc;
+    const bool io = i & 1, jo = jg & 1;
+    if (!io && !jo) return c[k];
+    if (!io && jo) return 0.5 * (c[k] + c[k + mc]);
+    if (io && !jo) return 0.5 * (c[k] + c[k + 1]);
+    double s = c[k] + c[k + 1];
+    s = s + c[k + mc];
+    s = s + c[k + mc + 1];
+    return 0.25 * s;
+}
+
+template <int ADD>
+__global__ __launch_bounds__(BX * BY) void k_refine(const double *__restrict__ coarse, int mc,
+                                                    double *__restrict__ fine, int mf, int jlo, int jhi, int gf0,
+                                                    int gc0)
+{
+    const int i = 1 + blockIdx.x * BX + threadIdx.x;
+    const int j = jlo + blockIdx.y * BY + threadIdx.y;
+    if (i >= mf - 1 || j >= jhi) return;
+    const size_t k = (size_t)i + (size_t)j * (size_t)mf;
+    const double p = prolong_at(coarse, mc, i, j + gf0, gc0);
+    if (ADD)
+        fine[k] = fine[k] + p;
+    else
+        fine[k] = p;
+}
+
+hipError_t launch_refine(const double *coarse, int mc, double *fine, int mf, int jlo, int jhi,
+                         int gf0, int gc0, int add, hipStream_t s)
+{
+    if (mf < 3 || jhi <= jlo) return hipSuccess;
+    if (add)
+        hipLaunchKernelGGL(k_refine<1>, grid2d(mf - 2, jhi - jlo), dim3(BX, BY), 0, s, coarse, mc, fine, mf, jlo,
+                           jhi, gf0, gc0);
+    else
+        hipLaunchKernelGGL(k_refine<0>, grid2d(mf - 2, jhi - jlo), dim3(BX, BY), 0, s, coarse, mc, fine, mf, jlo,
+                           jhi, gf0, gc0);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Coarsest solve on a 3x3 grid, reference main.cpp:165.
+// ---------------------------------------------------------------------------
+__global__ void k_direct3x3(double *__restrict__ u, const double *__restrict__ f, double h2)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = u[0 + 1 * 3] + u[2 + 1 * 3];
+    s = s + u[1 + 0 * 3];
+    s = s + u[1 + 2 * 3];
+    s = s - f[1 + 1 * 3] * h2;
+    u[1 + 1 * 3] = s * 0.25;
+}
+
+hipError_t launch_direct3x3(double *v, const double *f, double h2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_direct3x3, dim3(1), dim3(64), 0, s, v, f, h2);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Infinity norm, reference main.cpp:147-150 over DTDoubleArray.cpp:883-899,
+// 923-939: max(Maximum(a), -Minimum(a)) == max |a_k| over the non-NaN entries
+// (-inf if there are none).  max is exact and associative, so any reduction
+// tree gives the reference's bits.  Wavefront reduction by cross-lane
+// shuffles, one LDS hop across the workgroup's 4 waves, then ONE atomic max
+// per workgroup on the order-preserving integer image of the value.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double absmax_step(double acc, double v)
+{
+    const double a = __builtin_fabs(v);
+    return (acc < a) ? a : acc;  // NaN never wins, as `maxV < v ? v : maxV`
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off, 64);
+        v = (v < o) ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void block_max_to_slot(double acc, unsigned long long *slot)
+{
+    __shared__ double wmax[16];
+    const int tid = threadIdx.x + threadIdx.y * blockDim.x;
+    const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+    acc = wave_max(acc);
+    if ((tid & 63) == 0) wmax[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double v = wmax[0];
+        for (int w = 1; w < nw; w++) v = (v < wmax[w]) ? wmax[w] : v;
+        atomicMax(slot, norm_encode(v));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_norminf(const double *__restrict__ a, size_t len, unsigned long long *slot)
+{
+    double acc = -__builtin_inf();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < len; k += stride) acc = absmax_step(acc, a[k]);
+    block_max_to_slot(acc, slot);
+}
+
+hipError_t launch_norminf(const double *a, size_t len, unsigned long long *slot, hipStream_t s)
+{
+    size_t nb = (len + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb == 0) nb = 1;
+    hipLaunchKernelGGL(k_norminf, dim3((unsigned)nb), dim3(256), 0, s, a, len, slot);
+    return hipGetLastError();
+}
+
+// calcNorm(residual(p)) without writing the residual (main.cpp:307,351).
+// Boundary entries of the residual are +0.0, so the accumulator starts at
+// +0.0 instead of -inf.
+__global__ __launch_bounds__(BX * BY) void k_residual_norm(const double *__restrict__ u,
+                                                           const double *__restrict__ f, int m, int jlo, int jhi,
+                                                           SweepCoef c, unsigned long long *slot)
+{
+    const int i = 1 + blockIdx.x * BX + threadIdx.x;
+    double acc = 0.0;
+    if (i < m - 1) {
+        // each workgroup row (threadIdx.y) walks columns with stride gridDim.y*BY
+        for (int j = jlo + blockIdx.y * BY + threadIdx.y; j < jhi; j += gridDim.y * BY) {
+            const size_t k = (size_t)i + (size_t)j * (size_t)m;
+            acc = absmax_step(acc, residual_at(u, f, k, m, c.invh2));
+        }
+    }
+    block_max_to_slot(acc, slot);
+}
+
+hipError_t launch_residual_norm(const double *u, const double *f, int m, int jlo, int jhi, const SweepCoef &c,
+                                unsigned long long *slot, hipStream_t s)
+{
+    if (m < 3 || jhi <= jlo) return hipSuccess;
+    dim3 g = grid2d(m - 2, jhi - jlo);
+    // cap the number of workgroups (and atomics): about 16 per CU
+    const unsigned maxy = (4096 + g.x - 1) / g.x;
+    if (g.y > maxy) g.y = maxy;
+    hipLaunchKernelGGL(k_residual_norm, g, dim3(BX, BY), 0, s, u, f, m, jlo, jhi, c, slot);
+    return hipGetLastError();
+}
+
+} // namespace mgx

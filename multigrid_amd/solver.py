@@ -1,0 +1,276 @@
+"""Python mirror of the reference's solver interface over libmgx (HIP).
+
+Names, argument meaning and error behaviour follow the reference's main.cpp so
+that tests read like tests of the reference:
+
+    gridtype{f, v}                      main.cpp:29-33
+    MGOutputs{ResidualNorms, Times}     main.cpp:35-40
+    relax / residual / coarsen / refine / direct_solve / calcNorm / MultiGrid
+                                        main.cpp:147-357
+
+Arrays are torch float64 tensors on a GPU, indexed a[i, j] like the reference's
+DTDoubleArray(i, j) and stored COLUMN-MAJOR (stride 1 along i), which is what
+`colmajor()` / `to_device()` produce.  Everything here runs on the GPU through
+the C ABI; nothing falls back to the CPU.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("multigrid_amd needs a HIP GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU path")
+
+
+def colmajor(m, n, device="cuda", zero=True):
+    """m x n float64 tensor with column-major storage (a[i, j] at i + j*m)."""
+    base = (torch.zeros if zero else torch.empty)((n, m), dtype=torch.float64, device=device)
+    return base.t()
+
+
+def to_device(a, device="cuda"):
+    """numpy (any order) -> column-major GPU tensor with the same [i, j] indexing."""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim != 2:
+        raise ValueError("expected a 2-D array")
+    return torch.from_numpy(np.ascontiguousarray(a.T)).to(device).t()
+
+
+def to_numpy(t):
+    """column-major GPU tensor -> Fortran-ordered numpy array."""
+    return np.asfortranarray(t.t().contiguous().cpu().numpy().T)
+
+
+def _check_colmajor(t, name):
+    if t.dtype != torch.float64 or t.dim() != 2 or not t.is_cuda:
+        raise TypeError("%s must be a 2-D float64 GPU tensor" % name)
+    m, n = t.shape
+    if t.stride(0) != 1 or (n > 1 and t.stride(1) != m):
+        raise ValueError("%s must be column-major (use multigrid_amd.colmajor/to_device)" % name)
+    return m, n
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@dataclass
+class gridtype:
+    """main.cpp:29-33; dx replaces DTMutableMesh2D::Grid().dx()."""
+    f: torch.Tensor
+    v: torch.Tensor
+    dx: float
+
+
+@dataclass
+class MGOutputs:
+    """main.cpp:35-40."""
+    ResidualNorms: np.ndarray
+    Times: np.ndarray
+
+
+def _square_odd(t, name):
+    m, n = _check_colmajor(t, name)
+    if m != n:
+        raise ValueError("Error: Input is not square matrix!")       # main.cpp:410
+    if m % 2 == 0:
+        raise ValueError("Error: Input has even rows and columns!")  # main.cpp:415
+    return m
+
+
+def relax(p, Niter, omega):
+    """main.cpp:171-199: Niter damped-Jacobi sweeps on p.v, in place."""
+    _require_gpu()
+    m = _square_odd(p.v, "p.v")
+    _square_odd(p.f, "p.f")
+    L = _lib.load()
+    _lib.check(L.mgx_relax(p.v.data_ptr(), p.f.data_ptr(), m, p.dx, Niter, omega, _stream_ptr()))
+
+
+def residual(p):
+    """main.cpp:255-281: returns a new m x m array."""
+    _require_gpu()
+    m = _square_odd(p.v, "p.v")
+    r = colmajor(m, m, p.v.device, zero=False)
+    L = _lib.load()
+    _lib.check(L.mgx_residual(p.v.data_ptr(), p.f.data_ptr(), r.data_ptr(), m, p.dx, _stream_ptr()))
+    return r
+
+
+def coarsen(fine, coarse):
+    """main.cpp:201-221: restriction of `fine` into `coarse` (overwritten)."""
+    _require_gpu()
+    mf = _square_odd(fine, "fine")
+    mc, _ = _check_colmajor(coarse, "coarse")
+    L = _lib.load()
+    _lib.check(L.mgx_restrict(fine.data_ptr(), mf, coarse.data_ptr(), mc, _stream_ptr()))
+
+
+def refine(coarse, fine):
+    """main.cpp:223-253: bilinear interpolation of `coarse` into `fine` (overwritten)."""
+    _require_gpu()
+    mf = _square_odd(fine, "fine")
+    mc, _ = _check_colmajor(coarse, "coarse")
+    L = _lib.load()
+    _lib.check(L.mgx_refine(coarse.data_ptr(), mc, fine.data_ptr(), mf, _stream_ptr()))
+
+
+def prolong_add(coarse, v):
+    """refine() + `cur += refined` (main.cpp:339-341) without the temporary."""
+    _require_gpu()
+    mf = _square_odd(v, "v")
+    mc, _ = _check_colmajor(coarse, "coarse")
+    L = _lib.load()
+    _lib.check(L.mgx_prolong_add(coarse.data_ptr(), mc, v.data_ptr(), mf, _stream_ptr()))
+
+
+def direct_solve(p):
+    """main.cpp:153-169.  Returns False (and changes nothing) unless the grid is 3x3."""
+    _require_gpu()
+    m, _ = _check_colmajor(p.v, "p.v")
+    L = _lib.load()
+    rc = _lib.check(L.mgx_direct3x3(p.v.data_ptr(), p.f.data_ptr(), m, p.dx, _stream_ptr()))
+    return rc == 0
+
+
+def calcNorm(a):
+    """main.cpp:147-150: max(Maximum(a), -Minimum(a))."""
+    _require_gpu()
+    if a.dtype != torch.float64 or not a.is_cuda:
+        raise TypeError("calcNorm needs a float64 GPU tensor")
+    if a.dim() == 2:
+        _check_colmajor(a, "a")
+    elif not a.is_contiguous():
+        raise ValueError("calcNorm needs dense storage")
+    out = ctypes.c_double(0.0)
+    L = _lib.load()
+    _lib.check(L.mgx_norminf(a.data_ptr(), a.numel(), ctypes.byref(out), _stream_ptr()))
+    return out.value
+
+
+def residual_norm(p):
+    """calcNorm(residual(p)) in one pass (main.cpp:307,351)."""
+    _require_gpu()
+    m = _square_odd(p.v, "p.v")
+    out = ctypes.c_double(0.0)
+    L = _lib.load()
+    _lib.check(L.mgx_residual_norm(p.v.data_ptr(), p.f.data_ptr(), m, p.dx, ctypes.byref(out), _stream_ptr()))
+    return out.value
+
+
+class Plan:
+    """Device-resident level hierarchy (mgx_plan_*), reusable across solves."""
+
+    def __init__(self, m, dx, coarsest=2, schedule=_lib.SCHEDULE_DEFAULT, verbose=0):
+        _require_gpu()
+        self._L = _lib.load()
+        self._h = ctypes.c_void_p()
+        self.m = m
+        self.dx = dx
+        opt = _lib.make_options(device=torch.cuda.current_device(), stream=torch.cuda.current_stream().cuda_stream,
+                                schedule=schedule, verbose=verbose)
+        _lib.check(self._L.mgx_plan_create(ctypes.byref(self._h), m, dx, coarsest, ctypes.byref(opt)))
+
+    def close(self):
+        if self._h:
+            self._L.mgx_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def depth(self):
+        return self._L.mgx_plan_depth(self._h)
+
+    def level_m(self, d):
+        return self._L.mgx_plan_level_m(self._h, d)
+
+    @property
+    def nbytes(self):
+        return self._L.mgx_plan_bytes(self._h)
+
+    def set(self, f, v):
+        """Copy column-major GPU tensors f, v into the plan's fine level."""
+        m = self.m
+        for t, name in ((f, "f"), (v, "v")):
+            if _square_odd(t, name) != m:
+                raise ValueError("%s does not match the plan size %d" % (name, m))
+        _lib.check(self._L.mgx_plan_set_dev(self._h, f.data_ptr(), v.data_ptr()))
+
+    def get(self, out=None):
+        """The fine-level v as a column-major GPU tensor."""
+        m = self.m
+        if out is None:
+            out = colmajor(m, m, "cuda", zero=False)
+        elif _square_odd(out, "out") != m:
+            raise ValueError("out does not match the plan size %d" % m)
+        _lib.check(self._L.mgx_plan_get_dev(self._h, out.data_ptr()))
+        return out
+
+    def profile(self, enable=True):
+        """Start (and reset) or stop per-launch timing of the fine-level kernels."""
+        _lib.check(self._L.mgx_plan_profile(self._h, int(bool(enable))))
+
+    def profile_totals(self):
+        """{kernel name: (launch count, total milliseconds)} since profile(True)."""
+        out = {}
+        for k in range(_lib.KERNEL_COUNT):
+            n = ctypes.c_long(0)
+            ms = ctypes.c_double(0.0)
+            _lib.check(self._L.mgx_plan_profile_get(self._h, k, ctypes.byref(n), ctypes.byref(ms)))
+            if n.value:
+                out[self._L.mgx_kernel_name(k).decode()] = (n.value, ms.value)
+        return out
+
+    def cycles(self, Nv, Ndown, Nup, omega, pureJacobi=False):
+        res = np.zeros(Nv + 1)
+        tim = np.zeros(Nv + 1)
+        _lib.check(self._L.mgx_plan_cycles(self._h, Nv, Ndown, Nup, omega, int(bool(pureJacobi)),
+                                           res.ctypes.data, tim.ctypes.data))
+        return MGOutputs(res, tim)
+
+
+def MultiGrid(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi=False, schedule=_lib.SCHEDULE_DEFAULT):
+    """main.cpp:283-357: Nv V(Ndown,Nup) cycles; prob.v is overwritten in place.
+
+    Returns MGOutputs(ResidualNorms[Nv+1], Times[Nv+1])."""
+    _require_gpu()
+    m = _square_odd(prob.f, "prob.f")
+    if _square_odd(prob.v, "prob.v") != m:
+        raise ValueError("f and v differ in size")
+    plan = Plan(m, prob.dx, coarsest, schedule)
+    try:
+        plan.set(prob.f, prob.v)
+        out = plan.cycles(Nv, Ndown, Nup, omega, pureJacobi)
+        plan.get(out=prob.v)
+        torch.cuda.current_stream().synchronize()
+    finally:
+        plan.close()
+    return out
+
+
+def solve_host(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pureJacobi=False, schedule=_lib.SCHEDULE_DEFAULT):
+    """mgx_solve2d on host numpy arrays (the drop-in for main.cpp:445).
+
+    f, v: Fortran-ordered float64 m x n; v is overwritten.  Returns MGOutputs."""
+    f = np.asfortranarray(f, dtype=np.float64)
+    if not (isinstance(v, np.ndarray) and v.dtype == np.float64 and v.flags.f_contiguous):
+        raise TypeError("v must be a Fortran-ordered float64 numpy array (it is written in place)")
+    m, n = f.shape
+    res = np.zeros(Nv + 1)
+    tim = np.zeros(Nv + 1)
+    L = _lib.load()
+    opt = _lib.make_options(schedule=schedule)
+    _lib.check(L.mgx_solve2d(f.ctypes.data, v.ctypes.data, m, n, dx, Nv, Ndown, Nup, omega, coarsest,
+                             int(bool(pureJacobi)), res.ctypes.data, tim.ctypes.data, ctypes.byref(opt)))
+    return MGOutputs(res, tim)

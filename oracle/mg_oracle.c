@@ -1,0 +1,274 @@
+/*
+ * mg_oracle.c -- TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * Plain-C restatement of the 2D Poisson V-cycle of RoyJames/MultiGrid, used as
+ * the checker for the HIP path.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this file's shared object; the product
+ * library never links or calls it.
+ *
+ * Every function cites the reference lines it follows (paths relative to the
+ * reference checkout).  Arrays are column-major like DTDoubleArray
+ * (DTSource/DTDoubleArray.h:38-49): A(i,j) = a[i + j*m], i fastest.
+ *
+ * Build WITHOUT fast-math and WITHOUT FMA contraction
+ * (-O2 -ffp-contract=off): the left-to-right expression trees below are the
+ * definition of a correct result, bit for bit.
+ *
+ * Parity pin: the reference's main.cpp cannot be built in this image (it
+ * includes boost/program_options.hpp, which is absent, and stand-ins are not
+ * allowed), and the reference ships no tests or fixtures.  This restatement is
+ * pinned by the known answers captured from the reference when it was surveyed
+ * (tests/golden/reference_known_answers.json) and, for Maximum/Minimum/+=, by
+ * the reference's own DTSource sources compiled into oracle/_ref.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+#define IDX(i, j, m) ((size_t)(i) + (size_t)(j) * (size_t)(m))
+
+/* DTSource/DTDoubleArray.cpp:883-899 (Maximum) and :923-939 (Minimum):
+ * start at -inf / +inf, `maxV < v ? v : maxV`, so NaNs never win.
+ * main.cpp:147-150: calcNorm = max(Maximum(r), -Minimum(r)). */
+double mgo_maximum(const double *a, size_t len)
+{
+    double maxv = -INFINITY;
+    for (size_t k = 0; k < len; k++) {
+        double v = a[k];
+        maxv = (maxv < v ? v : maxv);
+    }
+    return maxv;
+}
+
+double mgo_minimum(const double *a, size_t len)
+{
+    double minv = INFINITY;
+    for (size_t k = 0; k < len; k++) {
+        double v = a[k];
+        minv = (minv > v ? v : minv);
+    }
+    return minv;
+}
+
+double mgo_calc_norm(const double *r, size_t len)
+{
+    double mx = mgo_maximum(r, len);
+    double mn = -mgo_minimum(r, len);
+    /* std::max<double>(a,b) = (a < b) ? b : a */
+    return (mx < mn) ? mn : mx;
+}
+
+/* main.cpp:171-199 relax(): Niter damped-Jacobi sweeps, each reading a full
+ * pre-sweep copy (:186) and writing the interior in place (:194-195). */
+void mgo_relax(double *u, const double *f, int m, double dx, int niter, double omega)
+{
+    double nomega = 1 - omega;
+    double h2 = dx * dx;
+    double factor = 0.25;
+    size_t len = (size_t)m * (size_t)m;
+    double *old = (double *)malloc(len * sizeof(double));
+    for (int it = 0; it < niter; it++) {
+        memcpy(old, u, len * sizeof(double));
+        for (int j = 1; j < m - 1; j++) {
+            for (int i = 1; i < m - 1; i++) {
+                double s = old[IDX(i - 1, j, m)] + old[IDX(i + 1, j, m)];
+                s = s + old[IDX(i, j - 1, m)];
+                s = s + old[IDX(i, j + 1, m)];
+                double fh = f[IDX(i, j, m)] * h2;
+                s = s - fh;
+                s = s * factor;
+                s = s * omega;
+                double a = old[IDX(i, j, m)] * nomega;
+                u[IDX(i, j, m)] = a + s;
+            }
+        }
+    }
+    free(old);
+}
+
+/* main.cpp:255-281 residual(): r = f - (uW+uE+uS+uN - 4 u) * (1/h2) on the
+ * interior, 0 elsewhere (:267). */
+void mgo_residual(const double *u, const double *f, double *r, int m, double dx)
+{
+    double h2 = dx * dx;
+    double invh2 = 1.0 / h2;
+    memset(r, 0, (size_t)m * (size_t)m * sizeof(double));
+    for (int j = 1; j < m - 1; j++) {
+        for (int i = 1; i < m - 1; i++) {
+            double s = u[IDX(i - 1, j, m)] + u[IDX(i + 1, j, m)];
+            s = s + u[IDX(i, j - 1, m)];
+            s = s + u[IDX(i, j + 1, m)];
+            double c4 = u[IDX(i, j, m)] * 4.0;
+            s = s - c4;
+            s = s * invh2;
+            r[IDX(i, j, m)] = f[IDX(i, j, m)] - s;
+        }
+    }
+}
+
+/* main.cpp:201-221 coarsen(): 9-point weighted restriction.  The corner term
+ * at :218 adds fine(2i+1,2j-1) twice and never fine(2i-1,2j+1); reproduced
+ * verbatim.  coarse is zeroed first (:211) so its boundary is 0. */
+void mgo_coarsen(const double *fine, int mf, double *coarse, int mc)
+{
+    double selfw = 1.0 / 4.0;
+    double neighborw = 1.0 / 8.0;
+    double cornerw = 1.0 / 16.0;
+    memset(coarse, 0, (size_t)mc * (size_t)mc * sizeof(double));
+    for (int i = 1; i < mc - 1; i++) {
+        for (int j = 1; j < mc - 1; j++) {
+            double a = fine[IDX(i * 2, j * 2, mf)] * selfw;
+            double nb = fine[IDX(i * 2 - 1, j * 2, mf)] + fine[IDX(i * 2 + 1, j * 2, mf)];
+            nb = nb + fine[IDX(i * 2, j * 2 - 1, mf)];
+            nb = nb + fine[IDX(i * 2, j * 2 + 1, mf)];
+            nb = nb * neighborw;
+            double cn = fine[IDX(i * 2 - 1, j * 2 - 1, mf)] + fine[IDX(i * 2 + 1, j * 2 - 1, mf)];
+            cn = cn + fine[IDX(i * 2 + 1, j * 2 - 1, mf)];
+            cn = cn + fine[IDX(i * 2 + 1, j * 2 + 1, mf)];
+            cn = cn * cornerw;
+            coarse[IDX(i, j, mc)] = (a + nb) + cn;
+        }
+    }
+}
+
+/* main.cpp:223-253 refine(): bilinear interpolation into a zeroed array. */
+void mgo_refine(const double *coarse, int mc, double *fine, int mf)
+{
+    memset(fine, 0, (size_t)mf * (size_t)mf * sizeof(double));
+    for (int j = 1; j < mf - 1; j++) {
+        for (int i = 1; i < mf - 1; i++) {
+            int I = i / 2, J = j / 2;
+            double v;
+            if (i % 2 == 0 && j % 2 == 0) {
+                v = coarse[IDX(I, J, mc)];
+            } else if (i % 2 == 0 && j % 2 == 1) {
+                v = 0.5 * (coarse[IDX(I, J, mc)] + coarse[IDX(I, J + 1, mc)]);
+            } else if (i % 2 == 1 && j % 2 == 0) {
+                v = 0.5 * (coarse[IDX(I, J, mc)] + coarse[IDX(I + 1, J, mc)]);
+            } else {
+                double s = coarse[IDX(I, J, mc)] + coarse[IDX(I + 1, J, mc)];
+                s = s + coarse[IDX(I, J + 1, mc)];
+                s = s + coarse[IDX(I + 1, J + 1, mc)];
+                v = 0.25 * s;
+            }
+            fine[IDX(i, j, mf)] = v;
+        }
+    }
+}
+
+/* DTSource/DTArrayTemplates.h:157-167 (operator+= on two arrays): flat loop
+ * over every entry, used at main.cpp:341. */
+void mgo_plus_equals(double *a, const double *b, size_t len)
+{
+    for (size_t k = 0; k < len; k++) a[k] = a[k] + b[k];
+}
+
+/* main.cpp:153-169 direct_solve(): closed form for the single unknown of a
+ * 3x3 grid; any other size prints the reference's message and changes nothing.
+ * Returns 0 if solved, 1 if the size is unsupported. */
+int mgo_direct_solve(double *u, const double *f, int m, double dx, int quiet)
+{
+    double h2 = dx * dx;
+    double factor = 0.25;
+    if (m == 3) {
+        double s = u[IDX(0, 1, 3)] + u[IDX(2, 1, 3)];
+        s = s + u[IDX(1, 0, 3)];
+        s = s + u[IDX(1, 2, 3)];
+        s = s - f[IDX(1, 1, 3)] * h2;
+        u[IDX(1, 1, 3)] = s * factor;
+        return 0;
+    }
+    if (!quiet) printf("Error: Direct solver not defined for %dx%d matrices!\n", m, m);
+    return 1;
+}
+
+/* main.cpp:286: depth = int(log2(1.0f*(M-1)/coarsest) + 0.5f), float math. */
+int mgo_depth(int m, int coarsest)
+{
+    float ratio = 1.0f * (float)(m - 1) / (float)coarsest;
+    return (int)(log2f(ratio) + 0.5f);
+}
+
+static double now_s(void)
+{
+    /* DTSource/DTTimer.h:13-19 uses gettimeofday wall time. */
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
+}
+
+/* main.cpp:283-357 MultiGrid(): level set-up (:286-300), Nv V(Ndown,Nup)
+ * cycles (:309-354), resnorm(0..Nv) and cumulative smoother-only times(0..Nv).
+ * f, v are the fine-level arrays (v in/out, boundary values already set).
+ * The unused `before`/`lowest` residual passes (:311,:332) have no effect on
+ * any output and are skipped.  Returns 0, or <0 for a hierarchy this
+ * restatement refuses (depth<0 or an even-sized level, where the reference
+ * indexes out of range). */
+int mgo_multigrid(const double *f, double *v, int m, double dx, int Nv, int Ndown, int Nup,
+                  double omega, int coarsest, int pure_jacobi, double *resnorm, double *times)
+{
+    if (m < 3 || (m % 2) == 0 || coarsest < 1) return -1;
+    int depth = mgo_depth(m, coarsest);
+    if (depth < 0) return -2;
+    int *dims = (int *)malloc((size_t)(depth + 1) * sizeof(int));
+    double *hs = (double *)malloc((size_t)(depth + 1) * sizeof(double));
+    dims[0] = m;
+    hs[0] = dx;
+    for (int d = 1; d <= depth; d++) {
+        dims[d] = (dims[d - 1] - 1) / 2 + 1; /* :293 */
+        hs[d] = hs[d - 1] * 2.0;             /* :297 */
+    }
+    for (int d = 0; d <= depth; d++) {
+        if (dims[d] < 3 || (dims[d] % 2) == 0) {
+            if (d > 0 || depth > 0) { free(dims); free(hs); return -3; }
+        }
+    }
+    double **F = (double **)calloc((size_t)(depth + 1), sizeof(double *));
+    double **V = (double **)calloc((size_t)(depth + 1), sizeof(double *));
+    size_t n0 = (size_t)m * (size_t)m;
+    F[0] = (double *)f; /* never written */
+    V[0] = v;           /* shared storage, main.cpp:288 */
+    for (int d = 1; d <= depth; d++) {
+        size_t nd = (size_t)dims[d] * (size_t)dims[d];
+        F[d] = (double *)calloc(nd, sizeof(double));
+        V[d] = (double *)calloc(nd, sizeof(double));
+    }
+    double *res = (double *)malloc(n0 * sizeof(double));
+    double *refined = (double *)malloc(n0 * sizeof(double));
+
+    mgo_residual(V[0], F[0], res, m, dx);
+    resnorm[0] = mgo_calc_norm(res, n0); /* :307 */
+    times[0] = 0;                        /* :308 */
+    for (int iter = 0; iter < Nv; iter++) {
+        double t_single = 0;
+        if (!pure_jacobi) {
+            for (int d = 0; d < depth; d++) { /* :317-328 */
+                double t0 = now_s();
+                mgo_relax(V[d], F[d], dims[d], hs[d], Ndown, omega);
+                t_single += now_s() - t0;
+                mgo_residual(V[d], F[d], res, dims[d], hs[d]);
+                mgo_coarsen(res, dims[d], F[d + 1], dims[d + 1]);
+            }
+            mgo_direct_solve(V[depth], F[depth], dims[depth], hs[depth], 0); /* :331 */
+            for (int d = depth - 1; d >= 0; d--) { /* :335-346 */
+                size_t nd = (size_t)dims[d] * (size_t)dims[d];
+                mgo_refine(V[d + 1], dims[d + 1], refined, dims[d]);
+                mgo_plus_equals(V[d], refined, nd);
+                double t0 = now_s();
+                mgo_relax(V[d], F[d], dims[d], hs[d], Nup, omega);
+                t_single += now_s() - t0;
+                memset(V[d + 1], 0, (size_t)dims[d + 1] * (size_t)dims[d + 1] * sizeof(double)); /* :345 */
+            }
+        } else {
+            mgo_relax(V[0], F[0], m, dx, 1, omega); /* :348 */
+        }
+        times[iter + 1] = times[iter] + t_single; /* :350 */
+        mgo_residual(V[0], F[0], res, m, dx);
+        resnorm[iter + 1] = mgo_calc_norm(res, n0); /* :351-353 */
+    }
+    for (int d = 1; d <= depth; d++) { free(F[d]); free(V[d]); }
+    free(F); free(V); free(res); free(refined); free(dims); free(hs);
+    return 0;
+}

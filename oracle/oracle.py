@@ -1,0 +1,147 @@
+"""ctypes loader for the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (multigrid_amd/) never does.
+
+All arrays are numpy float64, Fortran (column-major) order, matching
+DTDoubleArray (reference DTSource/DTDoubleArray.h:38-49).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 2 and not a.flags.f_contiguous:
+        a = np.asfortranarray(a)
+    return a
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libmg_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle not built: run `make -C oracle`")
+        L = ctypes.CDLL(path)
+        L.mgo_maximum.restype = ctypes.c_double
+        L.mgo_maximum.argtypes = [_dp, ctypes.c_size_t]
+        L.mgo_minimum.restype = ctypes.c_double
+        L.mgo_minimum.argtypes = [_dp, ctypes.c_size_t]
+        L.mgo_calc_norm.restype = ctypes.c_double
+        L.mgo_calc_norm.argtypes = [_dp, ctypes.c_size_t]
+        L.mgo_relax.restype = None
+        L.mgo_relax.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double]
+        L.mgo_residual.restype = None
+        L.mgo_residual.argtypes = [_dp, _dp, _dp, ctypes.c_int, ctypes.c_double]
+        L.mgo_coarsen.restype = None
+        L.mgo_coarsen.argtypes = [_dp, ctypes.c_int, _dp, ctypes.c_int]
+        L.mgo_refine.restype = None
+        L.mgo_refine.argtypes = [_dp, ctypes.c_int, _dp, ctypes.c_int]
+        L.mgo_plus_equals.restype = None
+        L.mgo_plus_equals.argtypes = [_dp, _dp, ctypes.c_size_t]
+        L.mgo_direct_solve.restype = ctypes.c_int
+        L.mgo_direct_solve.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+        L.mgo_depth.restype = ctypes.c_int
+        L.mgo_depth.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.mgo_multigrid.restype = ctypes.c_int
+        L.mgo_multigrid.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, _dp, _dp]
+        _LIB = L
+    return _LIB
+
+
+def ref_lib():
+    """The reference's own DTSource code (oracle/_ref), or None if not built."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "libdtref.so")
+        if not os.path.exists(path):
+            return None
+        L = ctypes.CDLL(path)
+        L.ref_maximum.restype = ctypes.c_double
+        L.ref_maximum.argtypes = [_dp, ctypes.c_long]
+        L.ref_minimum.restype = ctypes.c_double
+        L.ref_minimum.argtypes = [_dp, ctypes.c_long]
+        L.ref_plus_equals.restype = None
+        L.ref_plus_equals.argtypes = [_dp, _dp, ctypes.c_long]
+        L.ref_offset_of.restype = ctypes.c_long
+        L.ref_offset_of.argtypes = [ctypes.c_int] * 4
+        _REF = L
+    return _REF
+
+
+def calc_norm(r):
+    r = np.ascontiguousarray(np.asarray(r, dtype=np.float64).ravel(order="K"))
+    return lib().mgo_calc_norm(_ptr(r), r.size)
+
+
+def relax(u, f, dx, niter, omega):
+    """In-place on a copy; returns the new u (m x m, Fortran order)."""
+    u = _f64(u).copy(order="F")
+    f = _f64(f)
+    lib().mgo_relax(_ptr(u), _ptr(f), u.shape[0], dx, niter, omega)
+    return u
+
+
+def residual(u, f, dx):
+    u = _f64(u)
+    f = _f64(f)
+    r = np.empty_like(u, order="F")
+    lib().mgo_residual(_ptr(u), _ptr(f), _ptr(r), u.shape[0], dx)
+    return r
+
+
+def coarsen(fine):
+    fine = _f64(fine)
+    mf = fine.shape[0]
+    mc = (mf - 1) // 2 + 1
+    c = np.empty((mc, mc), dtype=np.float64, order="F")
+    lib().mgo_coarsen(_ptr(fine), mf, _ptr(c), mc)
+    return c
+
+
+def refine(coarse, mf=None):
+    coarse = _f64(coarse)
+    mc = coarse.shape[0]
+    if mf is None:
+        mf = 2 * (mc - 1) + 1
+    fine = np.empty((mf, mf), dtype=np.float64, order="F")
+    lib().mgo_refine(_ptr(coarse), mc, _ptr(fine), mf)
+    return fine
+
+
+def direct_solve(u, f, dx):
+    u = _f64(u).copy(order="F")
+    f = _f64(f)
+    rc = lib().mgo_direct_solve(_ptr(u), _ptr(f), u.shape[0], dx, 1)
+    return u, rc
+
+
+def depth(m, coarsest):
+    return lib().mgo_depth(m, coarsest)
+
+
+def multigrid(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pure_jacobi=False):
+    """Returns (Sol, ResNorms, Times) like main.cpp:445-455."""
+    f = _f64(f)
+    v = _f64(v).copy(order="F")
+    res = np.zeros(Nv + 1)
+    tim = np.zeros(Nv + 1)
+    rc = lib().mgo_multigrid(_ptr(f), _ptr(v), f.shape[0], dx, Nv, Ndown, Nup, omega, coarsest,
+                             int(bool(pure_jacobi)), _ptr(res), _ptr(tim))
+    if rc != 0:
+        raise ValueError("oracle refused the hierarchy (rc=%d)" % rc)
+    return v, res, tim

@@ -1,0 +1,166 @@
+"""GPU parity tests of the whole V-cycle driver (mgx_solve2d / mgx_plan_*)
+against the CPU oracle and the reference's known answers: Sol and the full
+ResNorms history must match bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits
+
+pytestmark = pytest.mark.gpu
+
+
+# 1 = one kernel per reference operator, 2 = fused streaming kernels
+SCHEDS = [1]
+
+
+def _case9():
+    m = 9
+    f = np.zeros((m, m), order="F")
+    for i in range(1, m - 1):
+        for j in range(1, m - 1):
+            f[i, j] = 1 + i + 10 * j
+    return m, 1.0 / 8, f
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+def test_known_answers_9(mg, known, sched):
+    K = known["case9"]["multigrid_5_3_3_0.6_2"]
+    m, h, f = _case9()
+    v = np.zeros((m, m), order="F")
+    out = mg.solve_host(f, v, h, 5, 3, 3, 0.6, 2, schedule=sched)
+    assert list(out.ResidualNorms) == [float(x) for x in K["ResNorms"]]
+    assert v[4, 4] == float(K["Sol(4,4)"])
+    assert out.Times[0] == 0 and np.all(np.diff(out.Times) >= 0)
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+def test_known_answers_257(mg, O, known, f_smooth_257, sched):
+    K = known["case257"]
+    M = 257
+    v = np.zeros((M, M), order="F")
+    out = mg.solve_host(f_smooth_257, v, 1.0 / (M - 1), 30, 2, 2, 0.6, 2, schedule=sched)
+    rn = out.ResidualNorms
+    assert list(rn[:6]) == [float(x) for x in K["ResNorms[0..5]"]]
+    assert rn[30] == float(K["ResNorms[30]"])
+    assert int(np.argmax(rn <= 1e-8)) == K["first_cycle_le_1e-8"]
+    assert v.max() == float(K["max(Sol)"])
+    sol, orn, _ = O.multigrid(f_smooth_257, np.zeros((M, M), order="F"), 1.0 / (M - 1), 30, 2, 2, 0.6, 2)
+    assert_bits(v, sol, "Sol 257")
+    assert_bits(rn, orn, "ResNorms 257")
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+@pytest.mark.parametrize("m,Nv,nd,nu,omega", [
+    (3, 3, 2, 2, 0.6), (5, 4, 2, 2, 0.6), (9, 5, 1, 2, 0.7), (17, 5, 2, 1, 0.8), (33, 8, 2, 2, 0.6),
+    (65, 6, 3, 3, 0.6), (129, 6, 5, 5, 0.9), (257, 5, 7, 7, 0.7), (513, 5, 2, 2, 0.6), (1025, 4, 2, 2, 0.6),
+    (129, 4, 0, 2, 0.6), (129, 4, 2, 0, 0.6), (65, 3, 0, 0, 0.6), (257, 4, 3, 2, 0.6), (257, 4, 1, 1, 0.6),
+])
+def test_solver_matches_oracle_random_rhs(mg, O, m, Nv, nd, nu, omega, sched):
+    from multigrid_amd import rhs
+    f = rhs.random_np(m)
+    dx = 1.0 / (m - 1)
+    rng = np.random.default_rng(m)
+    v0 = np.zeros((m, m), order="F")
+    # non-zero Dirichlet data and a non-zero interior guess: the API takes both
+    v0[0, :], v0[-1, :], v0[:, 0], v0[:, -1] = rng.standard_normal((4, m))
+    v0[1:-1, 1:-1] = rng.standard_normal((m - 2, m - 2)) * 0.01
+    sol, rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, 2)
+    v = v0.copy(order="F")
+    out = mg.solve_host(f, v, dx, Nv, nd, nu, omega, 2, schedule=sched)
+    assert_bits(out.ResidualNorms, rn, "ResNorms m=%d" % m)
+    assert_bits(v, sol, "Sol m=%d" % m)
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+@pytest.mark.parametrize("m,coarsest", [(257, 4), (129, 8), (65, 1), (33, 3), (5, 4)])
+def test_other_coarsest_values(mg, O, m, coarsest, sched):
+    # coarsest != 2 either ends on a grid larger than 3x3, where the reference's
+    # direct solver does nothing (main.cpp:167), or changes the depth (main.cpp:286).
+    from multigrid_amd import rhs
+    f = rhs.smooth_np(m)
+    dx = 1.0 / (m - 1)
+    v0 = np.zeros((m, m), order="F")
+    try:
+        sol, rn, _ = O.multigrid(f, v0, dx, 4, 2, 2, 0.6, coarsest)
+    except ValueError:
+        with pytest.raises(mg.MgxError):
+            mg.solve_host(f, v0.copy(order="F"), dx, 4, 2, 2, 0.6, coarsest, schedule=sched)
+        return
+    v = v0.copy(order="F")
+    out = mg.solve_host(f, v, dx, 4, 2, 2, 0.6, coarsest, schedule=sched)
+    assert_bits(out.ResidualNorms, rn, "ResNorms")
+    assert_bits(v, sol, "Sol")
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+def test_pure_jacobi(mg, O, sched):
+    from multigrid_amd import rhs
+    m = 65
+    f = rhs.random_np(m)
+    v0 = np.zeros((m, m), order="F")
+    sol, rn, _ = O.multigrid(f, v0, 1.0 / 64, 5, 2, 2, 0.6, 2, pure_jacobi=True)
+    v = v0.copy(order="F")
+    out = mg.solve_host(f, v, 1.0 / 64, 5, 2, 2, 0.6, 2, pureJacobi=True, schedule=sched)
+    assert_bits(out.ResidualNorms, rn, "ResNorms")
+    assert_bits(v, sol, "Sol")
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+def test_device_resident_api_and_repeated_calls(mg, O, sched):
+    """MultiGrid() on GPU tensors; 3 + 2 cycles through a Plan equal one 5-cycle call."""
+    from multigrid_amd import rhs
+    m = 129
+    dx = 1.0 / (m - 1)
+    f = rhs.random_np(m)
+    sol, rn, _ = O.multigrid(f, np.zeros((m, m), order="F"), dx, 5, 2, 2, 0.6, 2)
+    prob = mg.gridtype(mg.to_device(f), mg.colmajor(m, m), dx)
+    out = mg.MultiGrid(prob, 5, 2, 2, 0.6, 2, schedule=sched)
+    assert_bits(out.ResidualNorms, rn, "ResNorms")
+    assert_bits(mg.to_numpy(prob.v), sol, "Sol")
+    plan = mg.Plan(m, dx, 2, schedule=sched)
+    assert plan.depth == O.depth(m, 2) and plan.level_m(1) == 65
+    plan.set(mg.to_device(f), mg.colmajor(m, m))
+    a = plan.cycles(3, 2, 2, 0.6)
+    b = plan.cycles(2, 2, 2, 0.6)
+    assert_bits(np.concatenate([a.ResidualNorms, b.ResidualNorms[1:]]), rn, "split ResNorms")
+    assert a.ResidualNorms[-1] == b.ResidualNorms[0]
+    assert_bits(mg.to_numpy(plan.get()), sol, "split Sol")
+    plan.close()
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+def test_large_4097_against_oracle(mg, O, sched):
+    """BASELINE config 2 (4097^2, V(2,2)), 2 cycles: the oracle needs a few seconds."""
+    from multigrid_amd import rhs
+    m = 4097
+    dx = 1.0 / (m - 1)
+    f = rhs.random_np(m)
+    sol, rn, _ = O.multigrid(f, np.zeros((m, m), order="F"), dx, 2, 2, 2, 0.6, 2)
+    prob = mg.gridtype(rhs.random_torch(m), mg.colmajor(m, m), dx)
+    out = mg.MultiGrid(prob, 2, 2, 2, 0.6, 2, schedule=sched)
+    assert_bits(out.ResidualNorms, rn, "ResNorms 4097")
+    assert_bits(mg.to_numpy(prob.v), sol, "Sol 4097")
+
+
+def test_schedules_agree_at_16385(mg):
+    """BASELINE config 3 size: too big for the oracle in seconds, so the two
+    independent GPU schedules (one kernel per operator vs fused) must agree
+    bit for bit, and the residual history must contract."""
+    import torch
+    from multigrid_amd import rhs
+    if 2 not in SCHEDS:
+        pytest.skip("fused schedule not built yet")
+    m = 16385
+    dx = 1.0 / (m - 1)
+    f = rhs.random_torch(m)
+    outs = []
+    sols = []
+    for sched in (mg.SCHEDULE_STEPWISE, mg.SCHEDULE_FUSED):
+        prob = mg.gridtype(f, mg.colmajor(m, m), dx)
+        outs.append(mg.MultiGrid(prob, 3, 2, 2, 0.6, 2, schedule=sched))
+        sols.append(prob.v)
+    assert_bits(outs[0].ResidualNorms, outs[1].ResidualNorms, "ResNorms 16385")
+    assert torch.equal(sols[0].view(torch.int64) if False else sols[0], sols[1])
+    assert torch.equal(sols[0].t().contiguous().view(torch.int64), sols[1].t().contiguous().view(torch.int64))
+    rn = outs[0].ResidualNorms
+    assert rn[0] > rn[1] > rn[2] > rn[3] and rn[3] < 0.1 * rn[0]

@@ -1,0 +1,195 @@
+"""CPU tests: the oracle against the reference's known answers, against the
+reference's own DTSource code (oracle/_ref, when built) and against its frozen
+vectors.  No GPU, no product code."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits
+
+
+def _case9(O):
+    m = 9
+    h = 1.0 / 8
+    f = np.zeros((m, m), order="F")
+    for i in range(1, m - 1):
+        for j in range(1, m - 1):
+            f[i, j] = 1 + i + 10 * j
+    return m, h, f
+
+
+def _idx(key):
+    a, b = key.strip("()").split(",")
+    return int(a), int(b)
+
+
+def test_known_answers_operators_9(O, known):
+    K = known["case9"]
+    m, h, f = _case9(O)
+    u = O.relax(np.zeros((m, m), order="F"), f, h, 1, 0.6)
+    for key, val in K["relax_1_0.6"].items():
+        assert u[_idx(key)] == float(val), key
+    r = O.residual(u, f, h)
+    for key, val in K["residual_after_relax"].items():
+        if key == "norm":
+            assert O.calc_norm(r) == float(val)
+        else:
+            assert r[_idx(key)] == float(val), key
+    c = O.coarsen(r)
+    for key, val in K["coarsen_of_residual"].items():
+        assert c[_idx(key)] == float(val), key
+
+
+def test_known_answers_restriction_quirk(O, known):
+    # main.cpp:218: fine(2i+1,2j-1) enters twice, fine(2i-1,2j+1) never.
+    K = known["case9"]["coarsen_indicator"]
+    e = np.zeros((9, 9), order="F")
+    e[1, 3] = 1.0
+    assert O.coarsen(e)[1, 1] == float(K["fine(1,3)->c(1,1)"])
+    e = np.zeros((9, 9), order="F")
+    e[3, 1] = 1.0
+    assert O.coarsen(e)[1, 1] == float(K["fine(3,1)->c(1,1)"])
+    # the full 3x3 weight pattern seen by coarse (1,1)
+    w = np.zeros((3, 3))
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            e = np.zeros((9, 9), order="F")
+            e[2 + di, 2 + dj] = 1.0
+            w[di + 1, dj + 1] = O.coarsen(e)[1, 1]
+    expect = np.array([[1 / 16, 1 / 8, 0.0], [1 / 8, 1 / 4, 1 / 8], [2 / 16, 1 / 8, 1 / 16]])
+    assert np.array_equal(w, expect)
+
+
+def test_known_answers_refine(O, known):
+    K = known["case9"]["refine"]
+    c = np.zeros((5, 5), order="F")
+    for key, val in K["coarse"].items():
+        c[_idx(key)] = val
+    fine = O.refine(c)
+    for key, val in K["fine"].items():
+        assert fine[_idx(key)] == float(val), key
+    assert np.all(fine[0, :] == 0) and np.all(fine[-1, :] == 0) and np.all(fine[:, 0] == 0) and np.all(fine[:, -1] == 0)
+
+
+def test_known_answers_multigrid_9(O, known):
+    K = known["case9"]["multigrid_5_3_3_0.6_2"]
+    m, h, f = _case9(O)
+    sol, rn, tm = O.multigrid(f, np.zeros((m, m), order="F"), h, 5, 3, 3, 0.6, 2)
+    assert [float(x) for x in K["ResNorms"]] == list(rn)
+    assert sol[4, 4] == float(K["Sol(4,4)"])
+    assert tm[0] == 0 and np.all(np.diff(tm) >= 0)
+
+
+def test_known_answers_multigrid_257(O, known, f_smooth_257):
+    K = known["case257"]
+    M = 257
+    sol, rn, _ = O.multigrid(f_smooth_257, np.zeros((M, M), order="F"), 1.0 / (M - 1), 30, 2, 2, 0.6, 2)
+    assert list(rn[:6]) == [float(x) for x in K["ResNorms[0..5]"]]
+    assert rn[30] == float(K["ResNorms[30]"])
+    assert int(np.argmax(rn <= 1e-8)) == K["first_cycle_le_1e-8"]
+    assert sol.max() == float(K["max(Sol)"])
+
+
+def test_depth_rule(O):
+    # main.cpp:286 in float arithmetic
+    assert [O.depth(m, 2) for m in (3, 5, 9, 257, 4097, 16385, 32769)] == [0, 1, 2, 7, 11, 13, 14]
+    assert O.depth(257, 4) == 6
+    assert O.depth(3, 8) == -1  # int() truncates -1.5 toward zero
+
+
+def test_frozen_vectors(O, vectors33):
+    V = vectors33
+    u, f, c, dx = V["u"], V["f"], V["c"], float(V["dx"])
+    assert_bits(O.relax(u, f, dx, 3, 0.6), V["relax3_w06"], "relax3")
+    assert_bits(O.relax(u, f, dx, 1, 0.9), V["relax1_w09"], "relax1")
+    assert_bits(O.residual(u, f, dx), V["residual"], "residual")
+    assert_bits(O.coarsen(u), V["coarsen_u"], "coarsen")
+    assert_bits(O.refine(c), V["refine_c"], "refine")
+    assert O.calc_norm(u) == float(V["norm_u"])
+    sol, rn, _ = O.multigrid(f, np.zeros_like(u), dx, 8, 2, 2, 0.6, 2)
+    assert_bits(sol, V["mg_sol"], "mg_sol")
+    assert_bits(rn, V["mg_resnorms"], "mg_resnorms")
+
+
+def test_norm_semantics(O):
+    # DTDoubleArray.cpp:883-899,923-939: NaNs never win; main.cpp:149 combines max and -min.
+    assert O.calc_norm(np.array([1.0, -3.0, 2.0])) == 3.0
+    assert O.calc_norm(np.array([1.0, np.nan, -0.5])) == 1.0
+    assert O.calc_norm(np.array([-1.0, -2.0])) == 2.0
+    assert O.calc_norm(np.array([np.nan, np.nan])) == -np.inf
+    assert O.calc_norm(np.array([np.inf, 1.0])) == np.inf
+    assert O.calc_norm(np.array([-np.inf, 1.0])) == np.inf
+
+
+def test_direct_solve_only_3x3(O):
+    u = np.zeros((3, 3), order="F")
+    u[0, 1], u[2, 1], u[1, 0], u[1, 2] = 1.0, 2.0, 3.0, 4.0
+    f = np.zeros((3, 3), order="F")
+    f[1, 1] = 8.0
+    out, rc = O.direct_solve(u, f, 0.5)
+    assert rc == 0 and out[1, 1] == (1.0 + 2.0 + 3.0 + 4.0 - 8.0 * 0.25) * 0.25
+    u5 = np.ones((5, 5), order="F")
+    out5, rc = O.direct_solve(u5, np.ones((5, 5), order="F"), 0.25)
+    assert rc == 1 and np.array_equal(out5, u5)  # main.cpp:167: message, nothing changes
+
+
+def test_hierarchy_refusals(O):
+    with pytest.raises(ValueError):
+        O.multigrid(np.zeros((7, 7), order="F"), np.zeros((7, 7), order="F"), 1.0, 1, 1, 1, 0.6, 2)  # 7 -> 4 (even)
+    with pytest.raises(ValueError):
+        O.multigrid(np.zeros((3, 3), order="F"), np.zeros((3, 3), order="F"), 1.0, 1, 1, 1, 0.6, 8)  # depth -1
+
+
+def test_pure_jacobi_branch(O):
+    # main.cpp:347-349: one fine-grid sweep per "cycle"
+    rng = np.random.default_rng(3)
+    m = 17
+    f = np.asfortranarray(rng.standard_normal((m, m)))
+    v0 = np.zeros((m, m), order="F")
+    sol, rn, tm = O.multigrid(f, v0, 1.0 / 16, 4, 2, 2, 0.6, 2, pure_jacobi=True)
+    assert_bits(sol, O.relax(v0, f, 1.0 / 16, 4, 0.6), "pure jacobi")
+    assert np.all(tm == 0)
+
+
+# ---- against the reference's own DTSource code (oracle/_ref) -----------------
+
+def _ref(O):
+    R = O.ref_lib()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference checkout absent)")
+    return R
+
+
+def test_ref_maximum_minimum(O):
+    R = _ref(O)
+    rng = np.random.default_rng(11)
+    cases = [rng.standard_normal(1000), -np.abs(rng.standard_normal(257)), np.abs(rng.standard_normal(64)),
+             np.array([np.nan, 1.0, -2.0, np.nan]), np.array([np.nan]), np.array([0.0, -0.0]), np.array([-0.0, 0.0]),
+             np.array([np.inf, -np.inf, 3.0])]
+    for a in cases:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        p = a.ctypes.data_as(O._dp)
+        mx, mn = R.ref_maximum(p, a.size), R.ref_minimum(p, a.size)
+        assert_bits(np.array([O.lib().mgo_maximum(p, a.size)]), np.array([mx]), "Maximum")
+        assert_bits(np.array([O.lib().mgo_minimum(p, a.size)]), np.array([mn]), "Minimum")
+        expect = -mn if (mx < -mn) else mx  # std::max<double>(a,b) = (a<b)?b:a
+        assert_bits(np.array([O.calc_norm(a)]), np.array([expect]), "calcNorm")
+
+
+def test_ref_plus_equals(O):
+    R = _ref(O)
+    rng = np.random.default_rng(12)
+    a = rng.standard_normal(513)
+    b = rng.standard_normal(513)
+    a[0], b[0] = -0.0, 0.0
+    x = a.copy()
+    y = a.copy()
+    R.ref_plus_equals(x.ctypes.data_as(O._dp), b.ctypes.data_as(O._dp), a.size)
+    O.lib().mgo_plus_equals(y.ctypes.data_as(O._dp), b.ctypes.data_as(O._dp), a.size)
+    assert_bits(x, y, "operator+=")
+
+
+def test_ref_column_major(O):
+    R = _ref(O)
+    # DTDoubleArray.h:125-128: (i,j) -> i + j*m
+    for (m, n, i, j) in [(5, 5, 1, 0), (5, 5, 0, 1), (9, 7, 3, 4), (3, 3, 2, 2)]:
+        assert R.ref_offset_of(m, n, i, j) == i + j * m
