@@ -42,9 +42,18 @@ def algorithmic_bytes_per_point(kernel, nd, nu):
         "k_restrict": 10.0,
         "k_refine<1>": 18.0,
         "k_residual_norm": 16.0,
-        "k_fused_down": 24.0 * nd + 18.0,
-        "k_fused_up": 18.0 + 24.0 * nu,
+        "k_stream:down": 24.0 * nd + 18.0,
+        "k_stream:up": 18.0 + 24.0 * nu + 16.0,  # the level-0 up launch also yields the residual norm
     }[kernel]
+
+
+def rocprof_kernel_name(kernel, nd, nu):
+    """The name the fine-level launch carries in a rocprofv3 kernel trace."""
+    if kernel == "k_stream:down":
+        return "mgx::(anonymous namespace)::k_stream<false, %d, 1, false>" % nd
+    if kernel == "k_stream:up":
+        return "mgx::(anonymous namespace)::k_stream<true, %d, 2, false>" % nu
+    return "mgx::" + kernel
 
 
 def cycle_bytes(M, depth, nd, nu):
@@ -154,7 +163,7 @@ def main():
             pts = n0 / world
             bpp = algorithmic_bytes_per_point(kname, args.nd, args.nu)
             achieved = bpp * pts / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": rocprof_kernel_name(kname, args.nd, args.nu), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "launches": cnt, "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_point": bpp,
                     "points_per_launch": pts,

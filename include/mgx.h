@@ -180,6 +180,20 @@ int mgx_norminf(const double *a_dev, size_t len, double *out_host, void *stream)
  * (main.cpp:307,351). */
 int mgx_residual_norm(const double *v_dev, const double *f_dev, int m, double dx, double *out_host, void *stream);
 
+/* ---- fused legs (what the default schedule runs on every level) ------------ */
+
+/* Down leg of one level in one pass over HBM: relax(nsweeps) + residual +
+ * coarsen, main.cpp:321-327.  v_dev in/out (m*m); coarse_f_dev (mc*mc,
+ * mc=(m-1)/2+1) receives coarsen(residual(v)), boundary 0. */
+int mgx_fused_down(double *v_dev, const double *f_dev, double *coarse_f_dev, int m, double dx, int nsweeps,
+                   double omega, void *stream);
+
+/* Up leg of one level in one pass: refine + `cur += refined` + relax(nsweeps),
+ * main.cpp:337-344, and, if norm_host is not NULL, calcNorm(residual) of the
+ * result (main.cpp:351) from the same pass.  Synchronises the stream. */
+int mgx_fused_up(const double *coarse_v_dev, double *v_dev, const double *f_dev, int m, double dx, int nsweeps,
+                 double omega, double *norm_host, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,10 @@ SIGNATURES = {
     "mgx_prolong_add": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vp]),
     "mgx_direct3x3": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp]),
     "mgx_norminf": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp]),
+    "mgx_fused_down": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                      _vp]),
+    "mgx_fused_up": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                    _vp, _vp]),
     "mgx_residual_norm": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
 }
 

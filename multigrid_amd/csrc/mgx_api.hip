@@ -66,7 +66,7 @@ struct Level {
 struct mgx_plan {
     int device = 0;
     hipStream_t stream = nullptr;
-    int schedule = MGX_SCHEDULE_STEPWISE;
+    int schedule = MGX_SCHEDULE_FUSED;
     int verbose = 0;
     int coarsest = 2;
     int depth = 0;
@@ -202,6 +202,100 @@ int vcycle_stepwise(mgx_plan *p, int Ndown, int Nup, double omega)
     return MGX_OK;
 }
 
+
+StreamArgs level_args(const Level &L, const Level *C, double omega)
+{
+    StreamArgs A;
+    A.f = L.f;
+    A.m = L.m;
+    A.ld = L.m;
+    A.ncols = L.m;
+    A.jlo = 1;
+    A.jhi = L.m - 1;
+    A.jfix_lo = 0;
+    A.jfix_hi = L.m - 1;
+    A.c = make_coef(L.dx, omega);
+    if (C) {
+        A.mc = C->m;
+        A.ldc = C->m;
+        A.nccols = C->m;
+    }
+    return A;
+}
+
+// [prolong+correct] -> ns sweeps -> [residual -> restrict | norm] on one level
+// as a chain of fused launches of at most STREAM_MAX_SWEEPS sweeps each.
+// vbuf[cur] is the input iterate; every launch that writes the iterate writes
+// the other buffer and flips cur.  p may be null (no profiling).
+int stream_chain(mgx_plan *p, int level, int kid, hipStream_t s, int pro, int ns, int res, int zero_in,
+                 StreamArgs A, double *vbuf[2], int &cur)
+{
+    int remaining = ns;
+    bool first = true;
+    do {
+        const int k = remaining < STREAM_MAX_SWEEPS ? remaining : STREAM_MAX_SWEEPS;
+        remaining -= k;
+        const bool last = remaining == 0;
+        const int pr = first ? pro : 0;
+        const int rs = last ? res : 0;
+        const int zi = first ? zero_in : 0;
+        A.uin = vbuf[cur];
+        A.uout = vbuf[cur ^ 1];
+        if (k > 0 || pr || rs) {
+            if (p) {
+                LAUNCH(p, level, kid, launch_stream(pr, k, rs, zi, A, s));
+            } else {
+                HIP_TRY(launch_stream(pr, k, rs, zi, A, s));
+            }
+            if (k > 0 || pr) cur ^= 1;
+        }
+        first = false;
+    } while (remaining > 0);
+    return MGX_OK;
+}
+
+// One V(Ndown,Nup) cycle with the fused streaming kernels: per level one
+// launch on the way down (relax + residual + coarsen, main.cpp:321-327) and one
+// on the way up (refine + add + relax, main.cpp:337-344); on level 0 the up
+// launch also produces the residual norm of main.cpp:351 into norm_slot.
+int vcycle_fused(mgx_plan *p, int Ndown, int Nup, double omega, unsigned long long *norm_slot)
+{
+    const int depth = p->depth;
+    hipStream_t s = p->stream;
+    for (int d = 0; d < depth; d++) {
+        Level &L = p->lv[d];
+        Level &C = p->lv[d + 1];
+        StreamArgs A = level_args(L, &C, omega);
+        A.cout = C.f;
+        // a coarse level enters the down sweep with v == 0 (main.cpp:295-299,345): not read
+        const int zero_in = (d >= 1 && Ndown >= 1) ? 1 : 0;
+        int rc = stream_chain(p, d, MGX_KERNEL_FUSED_DOWN, s, 0, Ndown, 1, zero_in, A, L.v, L.cur);
+        if (rc) return rc;
+    }
+    {
+        Level &B = p->lv[depth];
+        if (B.m == 3) {
+            HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, s));
+        } else if (p->verbose) {
+            printf("Error: Direct solver not defined for %dx%d matrices!\n", B.m, B.m);
+        }
+    }
+    for (int d = depth - 1; d >= 0; d--) {
+        Level &L = p->lv[d];
+        Level &C = p->lv[d + 1];
+        StreamArgs A = level_args(L, &C, omega);
+        A.cin = C.v[C.cur];
+        const int res = (d == 0 && norm_slot) ? 2 : 0;
+        A.slot = norm_slot;
+        int rc = stream_chain(p, d, MGX_KERNEL_FUSED_UP, s, 1, Nup, res, 0, A, L.v, L.cur);
+        if (rc) return rc;
+        // main.cpp:345.  With Ndown >= 1 the next down sweep does not read the
+        // coarse iterate (zero_in), so the clear is only needed otherwise.
+        if (Ndown == 0) HIP_TRY(hipMemsetAsync(C.v[C.cur], 0, sizeof(double) * C.n(), s));
+    }
+    return MGX_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -247,7 +341,7 @@ int mgx_plan_create(mgx_plan **out, int m, double dx, int coarsest, const mgx_op
         }
         p->stream = (hipStream_t)opt->stream;
         p->verbose = opt->verbose;
-        p->schedule = opt->schedule == MGX_SCHEDULE_DEFAULT ? MGX_SCHEDULE_STEPWISE : opt->schedule;
+        p->schedule = opt->schedule == MGX_SCHEDULE_DEFAULT ? MGX_SCHEDULE_FUSED : opt->schedule;
         if (opt->device >= 0) {
             hipError_t e = hipSetDevice(opt->device);
             if (e != hipSuccess) {
@@ -256,7 +350,7 @@ int mgx_plan_create(mgx_plan **out, int m, double dx, int coarsest, const mgx_op
             }
         }
     }
-    if (p->schedule != MGX_SCHEDULE_STEPWISE) {
+    if (p->schedule != MGX_SCHEDULE_STEPWISE && p->schedule != MGX_SCHEDULE_FUSED) {
         delete p;
         return fail(MGX_ERR_ARG, "mgx_plan_create: schedule %d is not available", opt ? opt->schedule : -1);
     }
@@ -353,7 +447,7 @@ int mgx_plan_profile_get(const mgx_plan *p, int kernel_id, long *count, double *
 const char *mgx_kernel_name(int kernel_id)
 {
     static const char *names[MGX_KERNEL_COUNT] = {"k_jacobi", "k_residual", "k_restrict", "k_refine<1>",
-                                                  "k_residual_norm", "k_fused_down", "k_fused_up"};
+                                                  "k_residual_norm", "k_stream:down", "k_stream:up"};
     return (kernel_id >= 0 && kernel_id < MGX_KERNEL_COUNT) ? names[kernel_id] : "";
 }
 
@@ -413,14 +507,27 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
     LAUNCH(p, 0, MGX_KERNEL_RESNORM, launch_residual_norm(L0.v[L0.cur], L0.f, L0.m, 1, L0.m - 1, c0, p->slots + 0, s));
     HIP_TRY(hipEventRecord(p->events[0], s));
     for (int iter = 0; iter < Nv; iter++) {  // main.cpp:309
-        if (!pure_jacobi) {
+        unsigned long long *slot = p->slots + iter + 1;
+        bool norm_done = false;
+        if (p->schedule == MGX_SCHEDULE_FUSED) {
+            if (!pure_jacobi) {
+                rc = vcycle_fused(p, Ndown, Nup, omega, slot);
+                norm_done = p->depth > 0;
+            } else {  // main.cpp:348 with the norm of :351 in the same pass
+                StreamArgs A = level_args(L0, nullptr, omega);
+                A.slot = slot;
+                rc = stream_chain(p, 0, MGX_KERNEL_FUSED_UP, s, 0, 1, 2, 0, A, L0.v, L0.cur);
+                norm_done = true;
+            }
+        } else if (!pure_jacobi) {
             rc = vcycle_stepwise(p, Ndown, Nup, omega);
         } else {
             rc = level_relax(p, 0, 1, omega);  // main.cpp:348
         }
         if (rc) return rc;
         // main.cpp:351-353
-        LAUNCH(p, 0, MGX_KERNEL_RESNORM, launch_residual_norm(L0.v[L0.cur], L0.f, L0.m, 1, L0.m - 1, c0, p->slots + iter + 1, s));
+        if (!norm_done)
+            LAUNCH(p, 0, MGX_KERNEL_RESNORM, launch_residual_norm(L0.v[L0.cur], L0.f, L0.m, 1, L0.m - 1, c0, slot, s));
         HIP_TRY(hipEventRecord(p->events[iter + 1], s));
     }
     if (L0.cur != 0) {  // leave the solution in the buffer mgx_plan_v_dev() exposes
@@ -542,6 +649,72 @@ int mgx_direct3x3(double *v, const double *f, int m, double dx, void *stream)
     if (m != 3) return 1;  // main.cpp:167: message, no change
     HIP_TRY(launch_direct3x3(v, f, dx * dx, (hipStream_t)stream));
     return MGX_OK;
+}
+
+// v (in/out) through a temporary pong buffer: copies the boundary over, runs the
+// chain, copies the result back if it ended in the temporary.
+static int fused_on_copy(int pro, int ns, int res, StreamArgs A, double *v, size_t n, hipStream_t s)
+{
+    double *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, sizeof(double) * n));
+    int rc = MGX_OK;
+    hipError_t e = hipMemcpyAsync(tmp, v, sizeof(double) * n, hipMemcpyDeviceToDevice, s);
+    double *buf[2] = {v, tmp};
+    int cur = 0;
+    if (e == hipSuccess) rc = stream_chain(nullptr, 0, 0, s, pro, ns, res, 0, A, buf, cur);
+    if (e == hipSuccess && rc == MGX_OK && cur == 1) e = hipMemcpyAsync(v, tmp, sizeof(double) * n, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(MGX_ERR_HIP, "fused launch: %s", hipGetErrorString(e));
+    return MGX_OK;
+}
+
+int mgx_fused_down(double *v, const double *f, double *coarse_f, int m, double dx, int nsweeps, double omega, void *stream)
+{
+    if (!v || !f || !coarse_f) return fail(MGX_ERR_ARG, "mgx_fused_down: null pointer");
+    int rc = check_grid(m, "mgx_fused_down");
+    if (rc) return rc;
+    if (nsweeps < 0) return fail(MGX_ERR_ARG, "mgx_fused_down: negative sweep count");
+    hipStream_t s = (hipStream_t)stream;
+    Level L, C;
+    L.m = m; L.dx = dx; L.f = const_cast<double *>(f);
+    C.m = (m - 1) / 2 + 1;
+    StreamArgs A = level_args(L, &C, omega);
+    A.cout = coarse_f;
+    HIP_TRY(hipMemsetAsync(coarse_f, 0, sizeof(double) * C.n(), s));  // main.cpp:211
+    return fused_on_copy(0, nsweeps, 1, A, v, L.n(), s);
+}
+
+int mgx_fused_up(const double *coarse_v, double *v, const double *f, int m, double dx, int nsweeps, double omega,
+                 double *norm_host, void *stream)
+{
+    if (!v || !f || !coarse_v) return fail(MGX_ERR_ARG, "mgx_fused_up: null pointer");
+    int rc = check_grid(m, "mgx_fused_up");
+    if (rc) return rc;
+    if (nsweeps < 0) return fail(MGX_ERR_ARG, "mgx_fused_up: negative sweep count");
+    hipStream_t s = (hipStream_t)stream;
+    Level L, C;
+    L.m = m; L.dx = dx; L.f = const_cast<double *>(f);
+    C.m = (m - 1) / 2 + 1;
+    StreamArgs A = level_args(L, &C, omega);
+    A.cin = coarse_v;
+    unsigned long long *slot = nullptr;
+    if (norm_host) {
+        HIP_TRY(hipMalloc((void **)&slot, sizeof(*slot)));
+        hipError_t e = hipMemsetAsync(slot, 0, sizeof(*slot), s);
+        if (e != hipSuccess) { (void)hipFree(slot); return fail(MGX_ERR_HIP, "mgx_fused_up: %s", hipGetErrorString(e)); }
+        A.slot = slot;
+    }
+    rc = fused_on_copy(1, nsweeps, norm_host ? 2 : 0, A, v, L.n(), s);
+    if (!rc && norm_host) {
+        unsigned long long key = 0;
+        hipError_t e = hipMemcpy(&key, slot, sizeof(key), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(MGX_ERR_HIP, "mgx_fused_up: %s", hipGetErrorString(e));
+        *norm_host = norm_decode(key);
+    }
+    if (slot) (void)hipFree(slot);
+    return rc;
 }
 
 static int read_slot(unsigned long long *slot, double *out, hipStream_t s)

@@ -56,4 +56,28 @@ hipError_t launch_norminf(const double *a, size_t len, unsigned long long *slot,
 hipError_t launch_residual_norm(const double *u, const double *f, int m, int jlo, int jhi, const SweepCoef &c,
                                 unsigned long long *slot, hipStream_t s);
 
+// ---- fused streaming kernels (mgx_stream.hip) --------------------------------
+// One launch = [prolong + correct] -> ns Jacobi sweeps -> [residual -> restrict | norm].
+struct StreamArgs {
+    const double *uin = nullptr;  // fine iterate read (unused with zero_in)
+    double *uout = nullptr;       // fine iterate written (interior of [jlo,jhi) only)
+    const double *f = nullptr;    // fine right-hand side
+    const double *cin = nullptr;  // pro: coarse iterate to interpolate
+    double *cout = nullptr;       // res==1: coarse right-hand side written
+    unsigned long long *slot = nullptr;  // res==2: encoded norm, atomic max
+    int m = 0, ld = 0;            // fine rows and pitch (doubles)
+    int ncols = 0;                // fine local columns that exist: 0..ncols-1
+    int mc = 0, ldc = 0;          // coarse rows and pitch
+    int nccols = 0;               // coarse local columns that exist
+    int jlo = 0, jhi = 0;         // fine local columns to produce: [jlo, jhi)
+    int jfix_lo = -1, jfix_hi = -1;  // local index of the physical boundary columns j=0 / j=M-1, or -1
+    int gf0 = 0, gc0 = 0;         // global column index of local column 0 (fine, coarse)
+    int CJ = 0, nstrips = 0, nchunks = 0;  // filled by the launcher
+    SweepCoef c;
+};
+static constexpr int STREAM_MAX_SWEEPS = 4;
+// pro in {0,1}; ns in 0..STREAM_MAX_SWEEPS; res 0 none, 1 restrict into cout, 2 norm into slot;
+// zero_in: the input iterate is all zeros and is not read (needs ns >= 1, pro == 0).
+hipError_t launch_stream(int pro, int ns, int res, int zero_in, const StreamArgs &A, hipStream_t s);
+
 } // namespace mgx

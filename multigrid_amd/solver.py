@@ -164,6 +164,37 @@ def residual_norm(p):
     return out.value
 
 
+def fused_down(p, Niter, omega):
+    """relax(p, Niter, omega); coarsen(residual(p), coarse) in one pass (main.cpp:321-327).
+
+    p.v is updated in place; returns the coarse right-hand side (mc x mc)."""
+    _require_gpu()
+    m = _square_odd(p.v, "p.v")
+    _square_odd(p.f, "p.f")
+    mc = (m - 1) // 2 + 1
+    coarse = colmajor(mc, mc, p.v.device, zero=False)
+    L = _lib.load()
+    _lib.check(L.mgx_fused_down(p.v.data_ptr(), p.f.data_ptr(), coarse.data_ptr(), m, p.dx, Niter, omega,
+                                _stream_ptr()))
+    return coarse
+
+
+def fused_up(coarse, p, Niter, omega, norm=False):
+    """refine + `cur += refined` + relax(p, Niter, omega) in one pass (main.cpp:337-344);
+    with norm=True also returns calcNorm(residual(p)) of the result (main.cpp:351)."""
+    _require_gpu()
+    m = _square_odd(p.v, "p.v")
+    _square_odd(p.f, "p.f")
+    mc, _ = _check_colmajor(coarse, "coarse")
+    if mc != (m - 1) // 2 + 1:
+        raise ValueError("coarse size %d does not pair with fine size %d" % (mc, m))
+    out = ctypes.c_double(0.0)
+    L = _lib.load()
+    _lib.check(L.mgx_fused_up(coarse.data_ptr(), p.v.data_ptr(), p.f.data_ptr(), m, p.dx, Niter, omega,
+                              ctypes.byref(out) if norm else None, _stream_ptr()))
+    return out.value if norm else None
+
+
 class Plan:
     """Device-resident level hierarchy (mgx_plan_*), reusable across solves."""
 
