@@ -21,19 +21,29 @@
 // Mapping.  A wavefront owns a strip of 128 consecutive rows i (lane t holds
 // rows r0+2t and r0+2t+1 in registers) and marches along the columns j of a
 // chunk.  Column j of the input is loaded once (coalesced: the 64 lanes read
-// 1 KiB of one column); sweep s of column j-s is computed as soon as sweep s-1
-// of columns j-s-1..j-s+1 exists, so the NS sweeps, the residual and the
-// restriction form a software pipeline that lags the load front by NS+2
-// columns and never touches memory in between.  North/south neighbours (j-1,
-// j+1) are the lane's own registers of the previous/next column; west/east
-// neighbours (i-1, i+1) are the lane's other row or one cross-lane shift.
-// Waves are independent: no LDS, no barriers.  Strips overlap by the halo the
-// pipeline consumes (NS+2 rows below, NS+1 above), chunks by the same number
-// of columns; the overlap is recomputed, not communicated.
+// 1 KiB of one column, 16 B per lane); sweep s of column j-s is computed as
+// soon as sweep s-1 of columns j-s-1..j-s+1 exists, so the NS sweeps, the
+// residual and the restriction form a software pipeline that lags the load
+// front by NS+2 columns and never touches memory in between.  North/south
+// neighbours (j-1, j+1) are the lane's own registers of the previous/next
+// column; west/east neighbours (i-1, i+1) are the lane's other row or one
+// cross-lane shift.  Waves are independent: no LDS, no barriers.  Strips
+// overlap by the halo the pipeline consumes (NS+2 rows below, NS+1 above),
+// chunks by the same number of columns; the overlap is recomputed, not
+// communicated.
+//
+// The march is unrolled by two so that the parity of the column (which decides
+// the interpolation formula and when a coarse column is complete) is static,
+// and every load in the loop is unconditional (out-of-range columns and rows
+// are clamped to a valid address and the value is ignored): the compiler can
+// then count outstanding loads exactly and keep PF columns in flight per wave
+// instead of draining the queue every step.
 //
 // Every expression is evaluated exactly as in the stepwise kernels
 // (mgx_kernels.hip), so both schedules produce identical bits.
 #include "mgx_internal.h"
+
+#include <type_traits>
 
 namespace mgx {
 
@@ -82,19 +92,7 @@ __device__ __forceinline__ double residual_pt(double uW, double uE, double uS, d
 __device__ __forceinline__ double from_lower_lane(double v) { return __shfl_up(v, 1, 64); }    // lane t-1 -> t
 __device__ __forceinline__ double from_upper_lane(double v) { return __shfl_down(v, 1, 64); }  // lane t+1 -> t
 
-template <bool EDGE>
-__device__ __forceinline__ P2 load_pair(const double *__restrict__ p, bool ina, bool inb)
-{
-    P2 r;
-    if (EDGE) {
-        r.a = ina ? p[0] : 0.0;
-        r.b = inb ? p[1] : 0.0;
-    } else {
-        r.a = p[0];
-        r.b = p[1];
-    }
-    return r;
-}
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 template <bool PRO, int NS, int RES, bool ZERO_IN, bool EDGE>
 __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip, const int chunk)
@@ -110,42 +108,65 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
     const int own_lo = strip * G::S, own_hi = own_lo + G::S;
     const int r0 = own_lo - G::PADLO;
     const int ra = r0 + 2 * lane, rb = ra + 1;
-    const bool ina = !EDGE || (ra >= 0 && ra < m);
-    const bool inb = !EDGE || (rb >= 0 && rb < m);
     const bool fixa = EDGE && (ra <= 0 || ra >= m - 1);  // Dirichlet or outside: never updated
     const bool fixb = EDGE && (rb <= 0 || rb >= m - 1);
+    // own_lo, own_hi and ra are even, so away from the edges rows a and b are owned together
     const bool owna = ra >= own_lo && ra < own_hi && ra >= 1 && ra <= m - 2;
     const bool ownb = rb >= own_lo && rb < own_hi && rb >= 1 && rb <= m - 2;
+    // rows used for addressing: clamped into the array on edge strips, so that
+    // every load is unconditional (a clamped value belongs to a row that does
+    // not exist and never reaches an owned point)
+    const int ra_c = EDGE ? clampi(ra, 0, m - 1) : ra;
+    const int rb_c = EDGE ? clampi(rb, 0, m - 1) : rb;
 
     // ---- columns of this chunk -----------------------------------------------
     const int ja = A.jlo + chunk * A.CJ;
     const int jb = min(ja + A.CJ, A.jhi);
     int jstart = ja - G::HLC;
     if (jstart < 0) jstart = 0;
+    if ((jstart + A.gf0) & 1) jstart -= 1;  // start the march on an even global column
     const int jlast = jb + G::JLAST;
     const int ncols = A.ncols;
+    const int jfl = A.jfix_lo, jfh = A.jfix_hi;
 
-    const double *__restrict__ pu = A.uin + ra;
-    const double *__restrict__ pf = A.f + ra;
+    const double *__restrict__ pua = A.uin + ra_c;
+    const double *__restrict__ pub = A.uin + rb_c;
+    const double *__restrict__ pfa = A.f + ra_c;
+    const double *__restrict__ pfb = A.f + rb_c;
     double *__restrict__ po = A.uout + ra;
+
+    auto load_col = [&](const double *__restrict__ pa, const double *__restrict__ pb, int j) -> P2 {
+        const size_t off = (size_t)clampi(j, 0, ncols - 1) * ld;
+        P2 r;
+        r.a = pa[off];
+        r.b = pb[off];  // adjacent to r.a on interior strips: one 16-byte load
+        return r;
+    };
+    auto store_col = [&](int j, const P2 &v) {
+        if (EDGE) {
+            if (owna) po[(size_t)j * ld] = v.a;
+            if (ownb) po[(size_t)j * ld + 1] = v.b;
+        } else if (owna) {
+            double *q = po + (size_t)j * ld;
+            q[0] = v.a;
+            q[1] = v.b;
+        }
+    };
 
     // ---- prolongation state (PRO) -------------------------------------------
     // coarse row of this lane: I = ra/2 (ra is even); its upper neighbour I+1
     // comes from lane t+1.
     const int I = ra >> 1;
-    const bool inI = !EDGE || (I >= 0 && I < A.mc);
-    const double *__restrict__ pc = PRO ? (A.cin + I) : nullptr;
+    const int I_c = EDGE ? clampi(I, 0, A.mc - 1) : I;
+    const double *__restrict__ pc = PRO ? (A.cin + I_c) : nullptr;
+    auto load_c = [&](int J) -> double { return pc[(size_t)clampi(J, 0, A.nccols - 1) * (size_t)A.ldc]; };
     double c0 = 0, c0u = 0, c1 = 0, c1u = 0, cnext = 0;  // cols J, J+1 (own row, row I+1) and raw col J+2
-    int Jl = 0;                                          // local coarse column J of fine column jin
-    auto load_c = [&](int J) -> double {
-        return (inI && J >= 0 && J < A.nccols) ? pc[(size_t)J * (size_t)A.ldc] : 0.0;
-    };
+    int Jl = 0;                                          // local coarse column J of the current even column
     if (PRO) {
-        Jl = ((jstart + A.gf0) >> 1) - A.gc0;
-        c0 = load_c(Jl);
+        // primed one column back: the first (even) step rotates into place
+        Jl = ((jstart + A.gf0) >> 1) - A.gc0 - 1;
         c1 = load_c(Jl + 1);
         cnext = load_c(Jl + 2);
-        c0u = from_upper_lane(c0);
         c1u = from_upper_lane(c1);
     }
 
@@ -166,34 +187,29 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
     P2 Pu[PF], Pf[PF];
 #pragma unroll
     for (int k = 0; k < PF; k++) {
-        const int ju = jstart + k, jf = jstart - 1 + k;
-        Pu[k] = (!ZERO_IN && ju < ncols) ? load_pair<EDGE>(pu + (size_t)ju * ld, ina, inb) : P2{0.0, 0.0};
-        Pf[k] = (jf >= 0 && jf < ncols) ? load_pair<EDGE>(pf + (size_t)jf * ld, ina, inb) : P2{0.0, 0.0};
+        Pu[k] = ZERO_IN ? P2{0.0, 0.0} : load_col(pua, pub, jstart + k);
+        Pf[k] = load_col(pfa, pfb, jstart - 1 + k);
     }
 
     double nacc = 0.0;  // RES==2: running max |r| (boundary residuals are +0.0)
 
-    for (int jin = jstart; jin <= jlast; jin++) {
+    // One column step; ODD is the parity of the global column index of jin.
+    auto step = [&](const int jin, auto odd_tag) {
+        constexpr bool ODD = decltype(odd_tag)::value;
         // ---- take column jin from the load-ahead queue, refill it ----------
         P2 u0 = Pu[0];
-        P2 f1 = Pf[0];
+        const P2 f1 = Pf[0];
 #pragma unroll
         for (int k = 0; k + 1 < PF; k++) {
             Pu[k] = Pu[k + 1];
             Pf[k] = Pf[k + 1];
         }
-        {
-            const int ju = jin + PF, jf = jin - 1 + PF;
-            Pu[PF - 1] = (!ZERO_IN && ju < ncols && ju <= jlast) ? load_pair<EDGE>(pu + (size_t)ju * ld, ina, inb)
-                                                                 : P2{0.0, 0.0};
-            Pf[PF - 1] = (jf < ncols && jf <= jlast) ? load_pair<EDGE>(pf + (size_t)jf * ld, ina, inb) : P2{0.0, 0.0};
-        }
+        if (!ZERO_IN) Pu[PF - 1] = load_col(pua, pub, jin + PF);
+        Pf[PF - 1] = load_col(pfa, pfb, jin - 1 + PF);
 
         // ---- stage 0: the input iterate, plus the coarse-grid correction ------
         if (PRO) {
-            const int jg = jin + A.gf0;
-            const bool colfix = (jin == A.jfix_lo) || (jin == A.jfix_hi) || jin >= ncols;
-            if (jin > jstart && !(jg & 1)) {  // entered a new coarse column
+            if (!ODD) {  // entered a new coarse column
                 Jl += 1;
                 c0 = c1;
                 c0u = c1u;
@@ -201,21 +217,22 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
                 c1u = from_upper_lane(c1);
                 cnext = load_c(Jl + 2);
             }
-            if (!colfix) {
-                double pa, pb;
-                if (!(jg & 1)) {  // main.cpp:236, :242
-                    pa = c0;
-                    pb = 0.5 * (c0 + c0u);
-                } else {  // main.cpp:239, :245
-                    pa = 0.5 * (c0 + c1);
-                    double s4 = c0 + c0u;
-                    s4 = s4 + c1;
-                    s4 = s4 + c1u;
-                    pb = 0.25 * s4;
-                }
-                u0.a = fixa ? u0.a : u0.a + pa;  // main.cpp:341
-                u0.b = fixb ? u0.b : u0.b + pb;
+            double pa, pb;
+            if (!ODD) {  // main.cpp:236, :242
+                pa = c0;
+                pb = 0.5 * (c0 + c0u);
+            } else {  // main.cpp:239, :245
+                pa = 0.5 * (c0 + c1);
+                double s4 = c0 + c0u;
+                s4 = s4 + c1;
+                s4 = s4 + c1u;
+                pb = 0.25 * s4;
             }
+            const bool colfix = (jin == jfl) || (jin == jfh) || jin < 0 || jin >= ncols;
+            const double na = u0.a + pa;  // main.cpp:341
+            const double nb = u0.b + pb;
+            u0.a = (colfix || fixa) ? u0.a : na;
+            u0.b = (colfix || fixb) ? u0.b : nb;
         }
         U[0][0] = U[0][1];
         U[0][1] = U[0][2];
@@ -225,10 +242,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
         Fq[1] = f1;
 
         if (NS == 0 && PRO) {  // prolong + correct only: stage 0 is the output
-            if (jin >= ja && jin < jb && jin != A.jfix_lo && jin != A.jfix_hi) {
-                if (owna) po[(size_t)jin * ld] = u0.a;
-                if (ownb) po[(size_t)jin * ld + 1] = u0.b;
-            }
+            if (jin >= ja && jin < jb && jin != jfl && jin != jfh) store_col(jin, u0);
         }
 
         // ---- stages 1..NS: damped Jacobi sweeps ----------------------------------
@@ -236,24 +250,18 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
         for (int s = 1; s <= NS; s++) {
             const int jc = jin - s;
             const P2 uS = U[s - 1][0], uC = U[s - 1][1], uN = U[s - 1][2];
+            const bool colfix = (jc == jfl) || (jc == jfh);  // Dirichlet column: untouched by relax
+            const double wa = from_lower_lane(uC.b);         // row ra-1
+            const double eb = from_upper_lane(uC.a);         // row rb+1
+            const double na = jacobi_pt(wa, uC.b, uS.a, uN.a, uC.a, Fq[s].a, c);
+            const double nb = jacobi_pt(uC.a, eb, uS.b, uN.b, uC.b, Fq[s].b, c);
             P2 nw;
-            if (jc == A.jfix_lo || jc == A.jfix_hi) {
-                nw = uC;  // Dirichlet column: untouched by relax
-            } else {
-                const double wa = from_lower_lane(uC.b);  // row ra-1
-                const double eb = from_upper_lane(uC.a);  // row rb+1
-                const double na = jacobi_pt(wa, uC.b, uS.a, uN.a, uC.a, Fq[s].a, c);
-                const double nb = jacobi_pt(uC.a, eb, uS.b, uN.b, uC.b, Fq[s].b, c);
-                nw.a = fixa ? uC.a : na;
-                nw.b = fixb ? uC.b : nb;
-            }
+            nw.a = (colfix || fixa) ? uC.a : na;
+            nw.b = (colfix || fixb) ? uC.b : nb;
             U[s][0] = U[s][1];
             U[s][1] = U[s][2];
             U[s][2] = nw;
-            if (s == NS && jc >= ja && jc < jb && jc != A.jfix_lo && jc != A.jfix_hi) {
-                if (owna) po[(size_t)jc * ld] = nw.a;
-                if (ownb) po[(size_t)jc * ld + 1] = nw.b;
-            }
+            if (s == NS && jc >= ja && jc < jb && !colfix) store_col(jc, nw);
         }
 
         // ---- residual of stage NS at column jr ------------------------------------
@@ -266,36 +274,43 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
             r.a = residual_pt(wa, uC.b, uS.a, uN.a, uC.a, Fq[NS + 1].a, c);
             r.b = residual_pt(uC.a, eb, uS.b, uN.b, uC.b, Fq[NS + 1].b, c);
             if (RES == 2) {
-                if (jr >= ja && jr < jb && jr != A.jfix_lo && jr != A.jfix_hi) {
-                    const double xa = __builtin_fabs(r.a), xb = __builtin_fabs(r.b);
-                    if (owna) nacc = (nacc < xa) ? xa : nacc;
-                    if (ownb) nacc = (nacc < xb) ? xb : nacc;
-                }
+                const bool colok = jr >= ja && jr < jb && jr != jfl && jr != jfh;
+                const double xa = __builtin_fabs(r.a), xb = __builtin_fabs(r.b);
+                if (colok && owna) nacc = (nacc < xa) ? xa : nacc;
+                if (colok && ownb) nacc = (nacc < xb) ? xb : nacc;
             } else {
                 R[0] = R[1];
                 R[1] = R[2];
                 R[2] = r;
-                // coarse column J is centred on fine column 2J = jr-1 (global index even)
-                const int jcen = jr - 1;
-                const int jg = jcen + A.gf0;
-                if (!(jg & 1) && jcen >= ja && jcen < jb && jcen != A.jfix_lo && jcen != A.jfix_hi) {
-                    const double m1 = from_lower_lane(R[1].b);  // row 2I-1, column 2J
-                    const double m0 = from_lower_lane(R[0].b);  // row 2I-1, column 2J-1
-                    double t0 = R[1].a * 0.25;                  // main.cpp:216-218
-                    double nb = m1 + R[1].b;
-                    nb = nb + R[0].a;
-                    nb = nb + R[2].a;
-                    nb = nb * 0.125;
-                    double cn = m0 + R[0].b;
-                    cn = cn + R[0].b;
-                    cn = cn + R[2].b;
-                    cn = cn * 0.0625;
-                    const double outc = (t0 + nb) + cn;
-                    const int Jc = (jg >> 1) - A.gc0;
-                    if (owna && I >= 1 && I <= A.mc - 2) A.cout[(size_t)I + (size_t)Jc * (size_t)A.ldc] = outc;
+                // coarse column J is centred on the even fine column 2J = jr-1,
+                // complete once the odd column jr = 2J+1 has its residual
+                constexpr bool JR_ODD = ((NS + 1) & 1) ? !ODD : ODD;
+                if (JR_ODD) {
+                    const int jcen = jr - 1;
+                    if (jcen >= ja && jcen < jb && jcen != jfl && jcen != jfh) {
+                        const double m1 = from_lower_lane(R[1].b);  // row 2I-1, column 2J
+                        const double m0 = from_lower_lane(R[0].b);  // row 2I-1, column 2J-1
+                        const double t0 = R[1].a * 0.25;            // main.cpp:216-218
+                        double nb = m1 + R[1].b;
+                        nb = nb + R[0].a;
+                        nb = nb + R[2].a;
+                        nb = nb * 0.125;
+                        double cn = m0 + R[0].b;
+                        cn = cn + R[0].b;
+                        cn = cn + R[2].b;
+                        cn = cn * 0.0625;
+                        const double outc = (t0 + nb) + cn;
+                        const int Jc = ((jcen + A.gf0) >> 1) - A.gc0;
+                        if (owna && I >= 1 && I <= A.mc - 2) A.cout[(size_t)I + (size_t)Jc * (size_t)A.ldc] = outc;
+                    }
                 }
             }
         }
+    };
+
+    for (int jin = jstart; jin <= jlast; jin += 2) {
+        step(jin, std::false_type{});
+        step(jin + 1, std::true_type{});
     }
 
     if (RES == 2) {
