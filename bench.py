@@ -44,6 +44,7 @@ def algorithmic_bytes_per_point(kernel, nd, nu):
         "k_residual_norm": 16.0,
         "k_stream:down": 24.0 * nd + 18.0,
         "k_stream:up": 18.0 + 24.0 * nu + 16.0,  # the level-0 up launch also yields the residual norm
+        "k_stream:norm": 16.0,
     }[kernel]
 
 
@@ -53,6 +54,8 @@ def rocprof_kernel_name(kernel, nd, nu):
         return "mgx::(anonymous namespace)::k_stream<false, %d, 1, false>" % nd
     if kernel == "k_stream:up":
         return "mgx::(anonymous namespace)::k_stream<true, %d, 2, false>" % nu
+    if kernel == "k_stream:norm":
+        return "mgx::(anonymous namespace)::k_stream<false, 0, 2, false>"
     return "mgx::" + kernel
 
 
@@ -92,6 +95,8 @@ def main():
     ap.add_argument("--nu", type=int, default=2)
     ap.add_argument("--omega", type=float, default=0.6)
     ap.add_argument("--schedule", type=int, default=0, help="0 default, 1 stepwise, 2 fused")
+    ap.add_argument("--slab", action="store_true", help="run the j-slab driver even on one GPU")
+    ap.add_argument("--tail-m", type=int, default=2049, help="slab driver: first replicated (tail) level size")
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
     ap.add_argument("--cpu-size", type=int, default=0, help="grid size for the CPU baseline (0 = --size)")
     args = ap.parse_args()
@@ -106,10 +111,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    # one GPU per rank; MGX_DIST_BACKEND=gloo rehearses the multi-rank path on a box
+    # with fewer GPUs than ranks (ranks then share devices and stage halos on the host)
+    backend = os.environ.get("MGX_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     import multigrid_amd as mg
     from multigrid_amd import rhs
@@ -117,7 +130,7 @@ def main():
     M, K, W = args.size, args.steps, args.warmup
     dx = 1.0 / (M - 1)
 
-    if world == 1:
+    if world == 1 and not args.slab:
         plan = mg.Plan(M, dx, 2, schedule=args.schedule)
         plan.set(rhs.random_torch(M), mg.colmajor(M, M))
         solver = plan
@@ -125,7 +138,7 @@ def main():
         schedule_name = "single-gpu"
     else:
         from multigrid_amd import slab
-        solver = slab.SlabSolver(M, dx, 2, schedule=args.schedule)
+        solver = slab.SlabSolver(M, dx, 2, schedule=args.schedule, tail_m=args.tail_m)
         solver.set_random_rhs()
         depth = solver.depth
         schedule_name = "j-slabs x%d" % world

@@ -194,6 +194,61 @@ int mgx_fused_down(double *v_dev, const double *f_dev, double *coarse_f_dev, int
 int mgx_fused_up(const double *coarse_v_dev, double *v_dev, const double *f_dev, int m, double dx, int nsweeps,
                  double omega, double *norm_host, void *stream);
 
+/* ---- j-slab operator: the unit a multi-GPU driver launches ------------------
+ *
+ * The reference is single-process; this entry point has no counterpart there.
+ * It runs one fused leg ([refine + add] -> nsweeps x relax -> [residual ->
+ * coarsen | calcNorm], the operators of main.cpp:171-281) on a SLAB: an m-row
+ * column-major array holding `ncols` consecutive columns of a level, i.e. the
+ * columns one GPU owns plus the halo columns copied from its neighbours.
+ * Only columns [jlo, jhi) are produced; the columns around them are read as
+ * halo.  A slab that contains a physical boundary column (global j = 0 or
+ * j = M-1) names its local index in jfix_lo / jfix_hi (else -1); Dirichlet
+ * columns are never updated and end the halo requirement on that side.
+ * Without a fixed column on a side, the caller must supply, beyond the produced
+ * range, nsweeps (+2 on the left, +2 on the right when res == 1; +1 on both
+ * sides when res == 2) valid input columns of v_in and f; the call is rejected
+ * otherwise.  gf0 / gc0 are the GLOBAL column indices of local column 0 of the
+ * fine / coarse slab: global coarse column J pairs with global fine column 2J.
+ *   pro      1: stage 0 is v_in + P(coarse_v)
+ *   res      0: none; 1: coarsen(residual) of the produced columns with even
+ *            global index is written to coarse_f; 2: max |residual| over the
+ *            produced columns is merged (atomic max) into *norm_slot, encoded
+ *            as mgx_norm_decode() reads it
+ *   zero_in  1: v_in is all zeros and is not read (requires nsweeps >= 1, pro 0)
+ * v_out receives rows 1..m-2 of the produced columns (never a Dirichlet
+ * column) when pro or nsweeps >= 1; v_in and v_out must not overlap.
+ * Asynchronous on `stream`; nsweeps <= MGX_SLAB_MAX_SWEEPS per launch. */
+#define MGX_SLAB_MAX_SWEEPS 4
+typedef struct mgx_slab_op {
+    int struct_size;
+    int pro, nsweeps, res, zero_in;
+    const double *v_in;
+    double *v_out;
+    const double *f;
+    const double *coarse_v;
+    double *coarse_f;
+    unsigned long long *norm_slot;
+    int m, ld, ncols;       /* fine slab: rows, pitch (>= m), columns present   */
+    int mc, ldc, nccols;    /* coarse slab (pro or res == 1)                    */
+    int jlo, jhi;           /* fine local columns to produce                    */
+    int jfix_lo, jfix_hi;   /* local index of Dirichlet columns, or -1          */
+    int gf0, gc0;           /* global column index of local column 0            */
+    double dx, omega;
+} mgx_slab_op;
+int mgx_slab_launch(const mgx_slab_op *op, void *stream);
+
+/* Decode a norm slot written with res == 2 (0 decodes to -infinity: nothing
+ * merged yet).  Slots combine across GPUs by an integer MAX. */
+double mgx_norm_decode(unsigned long long slot);
+
+/* One V(Ndown,Nup) cycle of the plan, enqueued on its stream with no host
+ * synchronisation and no residual norm (a multi-GPU driver runs the coarse
+ * tail of the hierarchy through this).  zero_guess = 1: the fine iterate is
+ * taken to be all zeros, as a coarse level is when the down sweep reaches it
+ * (main.cpp:295-299,345); its Dirichlet boundary must then be zero too. */
+int mgx_plan_vcycle_async(mgx_plan *plan, int Ndown, int Nup, double omega, int zero_guess);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,23 @@ class mgx_options(ctypes.Structure):
     ]
 
 
+class mgx_slab_op(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_int),
+        ("pro", ctypes.c_int), ("nsweeps", ctypes.c_int), ("res", ctypes.c_int), ("zero_in", ctypes.c_int),
+        ("v_in", ctypes.c_void_p), ("v_out", ctypes.c_void_p), ("f", ctypes.c_void_p),
+        ("coarse_v", ctypes.c_void_p), ("coarse_f", ctypes.c_void_p), ("norm_slot", ctypes.c_void_p),
+        ("m", ctypes.c_int), ("ld", ctypes.c_int), ("ncols", ctypes.c_int),
+        ("mc", ctypes.c_int), ("ldc", ctypes.c_int), ("nccols", ctypes.c_int),
+        ("jlo", ctypes.c_int), ("jhi", ctypes.c_int),
+        ("jfix_lo", ctypes.c_int), ("jfix_hi", ctypes.c_int),
+        ("gf0", ctypes.c_int), ("gc0", ctypes.c_int),
+        ("dx", ctypes.c_double), ("omega", ctypes.c_double),
+    ]
+
+
+SLAB_MAX_SWEEPS = 4
+
 SCHEDULE_DEFAULT = 0
 SCHEDULE_STEPWISE = 1
 SCHEDULE_FUSED = 2
@@ -71,6 +88,9 @@ SIGNATURES = {
                                       _vp]),
     "mgx_fused_up": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double,
                                     _vp, _vp]),
+    "mgx_slab_launch": (ctypes.c_int, [_vp, _vp]),
+    "mgx_norm_decode": (ctypes.c_double, [ctypes.c_ulonglong]),
+    "mgx_plan_vcycle_async": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
     "mgx_residual_norm": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
 }
 

@@ -258,7 +258,7 @@ int stream_chain(mgx_plan *p, int level, int kid, hipStream_t s, int pro, int ns
 // launch on the way down (relax + residual + coarsen, main.cpp:321-327) and one
 // on the way up (refine + add + relax, main.cpp:337-344); on level 0 the up
 // launch also produces the residual norm of main.cpp:351 into norm_slot.
-int vcycle_fused(mgx_plan *p, int Ndown, int Nup, double omega, unsigned long long *norm_slot)
+int vcycle_fused(mgx_plan *p, int Ndown, int Nup, double omega, unsigned long long *norm_slot, bool zero0 = false)
 {
     const int depth = p->depth;
     hipStream_t s = p->stream;
@@ -268,7 +268,7 @@ int vcycle_fused(mgx_plan *p, int Ndown, int Nup, double omega, unsigned long lo
         StreamArgs A = level_args(L, &C, omega);
         A.cout = C.f;
         // a coarse level enters the down sweep with v == 0 (main.cpp:295-299,345): not read
-        const int zero_in = (d >= 1 && Ndown >= 1) ? 1 : 0;
+        const int zero_in = ((d >= 1 || zero0) && Ndown >= 1) ? 1 : 0;
         int rc = stream_chain(p, d, MGX_KERNEL_FUSED_DOWN, s, 0, Ndown, 1, zero_in, A, L.v, L.cur);
         if (rc) return rc;
     }
@@ -715,6 +715,103 @@ int mgx_fused_up(const double *coarse_v, double *v, const double *f, int m, doub
     }
     if (slot) (void)hipFree(slot);
     return rc;
+}
+
+int mgx_slab_launch(const mgx_slab_op *op, void *stream)
+{
+    if (!op) return fail(MGX_ERR_ARG, "mgx_slab_launch: null op");
+    if (op->struct_size != (int)sizeof(mgx_slab_op))
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: struct_size %d != %d", op->struct_size, (int)sizeof(mgx_slab_op));
+    const int ns = op->nsweeps, res = op->res, pro = op->pro ? 1 : 0, zi = op->zero_in ? 1 : 0;
+    if (ns < 0 || ns > MGX_SLAB_MAX_SWEEPS) return fail(MGX_ERR_ARG, "mgx_slab_launch: nsweeps %d outside 0..%d", ns, MGX_SLAB_MAX_SWEEPS);
+    if (res < 0 || res > 2) return fail(MGX_ERR_ARG, "mgx_slab_launch: res %d", res);
+    if (pro && res == 1) return fail(MGX_ERR_ARG, "mgx_slab_launch: pro with res == 1 is not a leg of the V-cycle");
+    if (zi && (pro || ns < 1 || res == 2)) return fail(MGX_ERR_ARG, "mgx_slab_launch: zero_in needs pro == 0, nsweeps >= 1, res != 2");
+    if (op->m < 3) return fail(MGX_ERR_ARG, "mgx_slab_launch: m %d < 3", op->m);
+    if (op->ld < op->m || op->ncols < 1) return fail(MGX_ERR_ARG, "mgx_slab_launch: bad pitch/ncols");
+    if (!op->f || (!zi && !op->v_in)) return fail(MGX_ERR_ARG, "mgx_slab_launch: null input");
+    const bool writes_v = pro || ns >= 1;
+    if (writes_v && !op->v_out) return fail(MGX_ERR_ARG, "mgx_slab_launch: null v_out");
+    if (writes_v && op->v_out == op->v_in) return fail(MGX_ERR_ARG, "mgx_slab_launch: v_out must not alias v_in");
+    if (!writes_v && res == 0) return MGX_OK;
+    if ((pro && !op->coarse_v) || (res == 1 && !op->coarse_f) || (res == 2 && !op->norm_slot))
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: null coarse array or norm slot");
+    if (op->jlo < 0 || op->jhi > op->ncols || op->jlo > op->jhi)
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: produced range [%d,%d) outside 0..%d", op->jlo, op->jhi, op->ncols);
+    if (op->jlo == op->jhi) return MGX_OK;
+    const int flo = op->jfix_lo, fhi = op->jfix_hi;
+    if ((flo >= 0 && flo != 0) || (fhi >= 0 && fhi != op->ncols - 1))
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: a Dirichlet column must be the first / last column of the slab");
+    if ((flo == 0 && op->jlo < 1) || (fhi >= 0 && op->jhi > fhi))
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: a Dirichlet column cannot be produced");
+    // halo the pipeline consumes around the produced columns
+    const int need_lo = ns + (res == 1 ? 2 : res == 2 ? 1 : 0);
+    const int need_hi = ns + (res == 1 ? 2 : res == 2 ? 1 : 0);
+    if (flo < 0 && op->jlo - need_lo < 0)
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: %d halo columns needed left of column %d", need_lo, op->jlo);
+    if (fhi < 0 && op->jhi - 1 + need_hi > op->ncols - 1)
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: %d halo columns needed right of column %d", need_hi, op->jhi - 1);
+    if (pro || res == 1) {
+        if (op->mc != (op->m - 1) / 2 + 1 || op->ldc < op->mc || op->nccols < 1)
+            return fail(MGX_ERR_ARG, "mgx_slab_launch: coarse slab %d rows does not pair with %d fine rows", op->mc, op->m);
+        // coarse columns touched: interpolation reads J and J+1 of every input
+        // column, restriction writes J of the produced even columns
+        int jf_lo = op->jlo, jf_hi = op->jhi - 1;
+        if (pro) {
+            jf_lo = op->jlo - need_lo < 0 ? 0 : op->jlo - need_lo;
+            jf_hi = op->jhi - 1 + need_hi > op->ncols - 1 ? op->ncols - 1 : op->jhi - 1 + need_hi;
+        }
+        const int Jlo = ((jf_lo + op->gf0) >> 1) - op->gc0;
+        const int Jhi = ((jf_hi + op->gf0 + (pro ? 1 : 0)) >> 1) - op->gc0;
+        if (Jlo < 0 || Jhi > op->nccols - 1)
+            return fail(MGX_ERR_ARG, "mgx_slab_launch: coarse columns %d..%d outside the coarse slab 0..%d", Jlo, Jhi,
+                        op->nccols - 1);
+    }
+    if (!(op->dx > 0.0)) return fail(MGX_ERR_ARG, "mgx_slab_launch: dx must be positive");
+    StreamArgs A;
+    A.uin = op->v_in;
+    A.uout = op->v_out;
+    A.f = op->f;
+    A.cin = op->coarse_v;
+    A.cout = op->coarse_f;
+    A.slot = op->norm_slot;
+    A.m = op->m;
+    A.ld = op->ld;
+    A.ncols = op->ncols;
+    A.mc = op->mc;
+    A.ldc = op->ldc;
+    A.nccols = op->nccols;
+    A.jlo = op->jlo;
+    A.jhi = op->jhi;
+    A.jfix_lo = flo;
+    A.jfix_hi = fhi;
+    A.gf0 = op->gf0;
+    A.gc0 = op->gc0;
+    A.c = make_coef(op->dx, op->omega);
+    HIP_TRY(launch_stream(pro, ns, res, zi, A, (hipStream_t)stream));
+    return MGX_OK;
+}
+
+double mgx_norm_decode(unsigned long long slot) { return norm_decode(slot); }
+
+int mgx_plan_vcycle_async(mgx_plan *p, int Ndown, int Nup, double omega, int zero_guess)
+{
+    if (!p) return fail(MGX_ERR_ARG, "mgx_plan_vcycle_async: null plan");
+    if (Ndown < 0 || Nup < 0) return fail(MGX_ERR_ARG, "mgx_plan_vcycle_async: negative count");
+    if (zero_guess && !(p->schedule == MGX_SCHEDULE_FUSED && Ndown >= 1)) {
+        // the schedule will read the iterate: make it zero in memory
+        Level &L = p->lv[0];
+        HIP_TRY(hipMemsetAsync(L.v[L.cur], 0, sizeof(double) * L.n(), p->stream));
+    }
+    int rc = p->schedule == MGX_SCHEDULE_FUSED ? vcycle_fused(p, Ndown, Nup, omega, nullptr, zero_guess != 0)
+                                               : vcycle_stepwise(p, Ndown, Nup, omega);
+    if (rc) return rc;
+    Level &L0 = p->lv[0];
+    if (L0.cur != 0) {  // keep the result in the buffer mgx_plan_v_dev() exposes
+        HIP_TRY(hipMemcpyAsync(L0.v[0], L0.v[1], sizeof(double) * L0.n(), hipMemcpyDeviceToDevice, p->stream));
+        L0.cur = 0;
+    }
+    return MGX_OK;
 }
 
 static int read_slot(unsigned long long *slot, double *out, hipStream_t s)

@@ -99,3 +99,25 @@ def random_torch(M, seed=SEED, device="cuda"):
     u[:, 0] = 0.0
     u[:, -1] = 0.0
     return u.contiguous().t()
+
+
+def random_torch_cols(M, j0, j1, seed=SEED, device="cuda"):
+    """Columns j0..j1-1 of random_np(M, seed) as a (j1-j0, M) GPU tensor whose row k
+    is column j0+k of the grid (the slab layout of multigrid_amd.slab)."""
+    import torch
+    i = torch.arange(M, dtype=torch.int64, device=device)[None, :]
+    j = torch.arange(j0, j1, dtype=torch.int64, device=device)[:, None]
+    k = i + j * M
+    z = k ^ _wrap(seed)
+    z = z + _wrap(0x9E3779B97F4A7C15)
+    z = (z ^ _lsr(z, 30)) * _wrap(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * _wrap(0x94D049BB133111EB)
+    z = z ^ _lsr(z, 31)
+    u = _lsr(z, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+    u[:, 0] = 0.0
+    u[:, -1] = 0.0
+    if j0 == 0:
+        u[0, :] = 0.0
+    if j1 == M:
+        u[-1, :] = 0.0
+    return u.contiguous()

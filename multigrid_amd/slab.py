@@ -1,0 +1,447 @@
+"""Multi-GPU V-cycle: j-slab decomposition, one process per GPU.
+
+The reference is single-process (main.cpp); this module is the multi-device
+driver of the same V-cycle (main.cpp:283-357) and produces the same bits.
+
+Decomposition.  Every level is column-major, so a contiguous range of columns j
+is one contiguous block of memory.  The finest `ndist` levels are DISTRIBUTED:
+rank g owns the columns [b_g, b_{g+1}) of a level and stores them together with
+W halo columns copied from each neighbour.  Ownership is nested,
+b_g(fine) = 2*b_g(coarse) - 1, so the rank that owns fine column 2J owns coarse
+column J and both level transfers are local apart from the halo.  Levels from
+the first one with at most `tail_m` points per side downwards form the TAIL: its
+right-hand side is all-gathered and every rank runs the tail redundantly on its
+own GPU (identical bits everywhere), which removes the scatter on the way up.
+
+Per cycle and distributed level there are two neighbour exchanges (after the
+down leg: the smoothed iterate and the next coarser right-hand side in one
+batch; after the up leg: the corrected iterate) and one all-gather at the tail.
+Exchanges are plain point-to-point send/recv of whole columns through
+torch.distributed: RCCL over xGMI with backend "nccl", or gloo for tests.
+
+The arithmetic runs through a backend object.  The product backend is
+HipBackend (libmgx's mgx_slab_launch / mgx_plan_vcycle_async); tests inject a
+CPU backend to exercise this driver under gloo without a GPU.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .solver import MGOutputs
+
+
+class SlabOp:
+    """Arguments of one fused slab launch (mirrors mgx_slab_op in include/mgx.h)."""
+    __slots__ = ("pro", "nsweeps", "res", "zero_in", "v_in", "v_out", "f", "coarse_v", "coarse_f", "norm_slot",
+                 "m", "ncols", "mc", "nccols", "jlo", "jhi", "jfix_lo", "jfix_hi", "gf0", "gc0", "dx", "omega")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+class HipBackend:
+    """Slab arithmetic on the GPU through libmgx.  Arrays are torch float64 CUDA
+    tensors of shape (ncols, m): row k of the tensor is column k of the slab."""
+    name = "hip"
+
+    def __init__(self, schedule=_lib.SCHEDULE_DEFAULT):
+        if not torch.cuda.is_available():
+            raise RuntimeError("multigrid_amd.slab: HipBackend needs a GPU; there is no CPU path")
+        self.L = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.schedule = schedule
+
+    def zeros(self, ncols, m):
+        return torch.zeros((ncols, m), dtype=torch.float64, device=self.device)
+
+    def slots(self, n):
+        return torch.zeros(n, dtype=torch.int64, device=self.device)
+
+    def from_numpy(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def to_numpy(self, t):
+        return t.cpu().numpy()
+
+    def comm_tensor(self, t):
+        return t
+
+    def launch(self, op):
+        o = _lib.mgx_slab_op()
+        o.struct_size = ctypes.sizeof(_lib.mgx_slab_op)
+        o.pro, o.nsweeps, o.res, o.zero_in = int(op.pro), int(op.nsweeps), int(op.res), int(op.zero_in)
+        o.v_in = op.v_in.data_ptr() if op.v_in is not None else None
+        o.v_out = op.v_out.data_ptr() if op.v_out is not None else None
+        o.f = op.f.data_ptr()
+        o.coarse_v = op.coarse_v.data_ptr() if op.coarse_v is not None else None
+        o.coarse_f = op.coarse_f.data_ptr() if op.coarse_f is not None else None
+        o.norm_slot = op.norm_slot
+        o.m, o.ld, o.ncols = op.m, op.m, op.ncols
+        o.mc, o.ldc, o.nccols = op.mc or 0, op.mc or 0, op.nccols or 0
+        o.jlo, o.jhi, o.jfix_lo, o.jfix_hi = op.jlo, op.jhi, op.jfix_lo, op.jfix_hi
+        o.gf0, o.gc0 = op.gf0, op.gc0 or 0
+        o.dx, o.omega = op.dx, op.omega
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(self.L.mgx_slab_launch(ctypes.byref(o), stream))
+
+    def slot_ptr(self, slots, k):
+        return slots.data_ptr() + 8 * k
+
+    def decode_slots(self, slots):
+        keys = slots.cpu().numpy().astype(np.uint64)
+        return np.array([self.L.mgx_norm_decode(int(k)) for k in keys])
+
+    def make_tail(self, m, dx, coarsest):
+        return _HipTail(self, m, dx, coarsest)
+
+    def synchronize(self):
+        torch.cuda.current_stream().synchronize()
+
+
+class _HipTail:
+    """The replicated coarse tail: a single-GPU plan of the tail's finest level."""
+
+    def __init__(self, be, m, dx, coarsest):
+        self.be = be
+        self.m = m
+        self.h = ctypes.c_void_p()
+        opt = _lib.make_options(device=torch.cuda.current_device(), stream=torch.cuda.current_stream().cuda_stream,
+                                schedule=be.schedule)
+        _lib.check(be.L.mgx_plan_create(ctypes.byref(self.h), m, dx, coarsest, ctypes.byref(opt)))
+        self.v = be.zeros(m, m)
+
+    def run(self, f_full, Ndown, Nup, omega):
+        """v = one V(Ndown,Nup) cycle from a zero guess for the right-hand side f_full."""
+        L = self.be.L
+        _lib.check(L.mgx_plan_set_dev(self.h, f_full.data_ptr(), None))
+        _lib.check(L.mgx_plan_vcycle_async(self.h, Ndown, Nup, omega, 1))
+        _lib.check(L.mgx_plan_get_dev(self.h, self.v.data_ptr()))
+        return self.v
+
+    def close(self):
+        if self.h:
+            self.be.L.mgx_plan_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+
+class _Comm:
+    """Neighbour exchange and collectives over torch.distributed (or a single rank)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.size = dist.get_world_size(group) if self.on else 1
+        self.backend = dist.get_backend(group) if self.on else "none"
+        self._tag = 0
+
+    def _global(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def _stage(self, t):
+        # gloo moves host memory: stage device tensors through the host
+        return t.cpu() if (self.backend == "gloo" and t.is_cuda) else t
+
+    def exchange(self, items):
+        """items: list of (tensor, send_lo, recv_lo, send_hi, recv_hi) where each entry but
+        the tensor is a (start, stop) row range or None.  *_lo talk to rank-1, *_hi to rank+1."""
+        if self.size == 1:
+            return
+        ops, copies = [], []
+        for idx, (t, s_lo, r_lo, s_hi, r_hi) in enumerate(items):
+            for (rng, peer, is_send, side) in ((r_lo, self.rank - 1, False, 0), (r_hi, self.rank + 1, False, 1),
+                                               (s_lo, self.rank - 1, True, 1), (s_hi, self.rank + 1, True, 0)):
+                if rng is None or peer < 0 or peer >= self.size:
+                    continue
+                view = t[rng[0]:rng[1]]
+                # a message is tagged by (item, which side of the RECEIVER it fills)
+                tag = 2 * idx + side
+                if is_send:
+                    buf = self._stage(view)
+                    ops.append((dist.isend, buf, peer, tag))
+                else:
+                    buf = self._stage(view) if not (self.backend == "gloo" and view.is_cuda) else torch.empty(
+                        view.shape, dtype=view.dtype)
+                    if buf is not view:
+                        copies.append((view, buf))
+                    ops.append((dist.irecv, buf, peer, tag))
+        if self.backend == "nccl":
+            reqs = dist.batch_isend_irecv([dist.P2POp(fn, buf, self._global(peer), self.group) for (fn, buf, peer, _)
+                                           in ops])
+        else:
+            reqs = [fn(buf, self._global(peer), group=self.group, tag=tag) for (fn, buf, peer, tag) in ops]
+        for r in reqs:
+            r.wait()
+        for view, buf in copies:
+            view.copy_(buf)
+
+    def allgather(self, t):
+        """Concatenation over ranks of equally shaped tensors along dim 0."""
+        if self.size == 1:
+            return t
+        src = self._stage(t).contiguous()
+        out = torch.empty((self.size * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather(list(out.chunk(self.size, 0)), src, group=self.group)
+        return out.to(t.device) if out.device != t.device else out
+
+    def allreduce_max_(self, t):
+        if self.size == 1:
+            return t
+        buf = self._stage(t)
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
+        if buf is not t:
+            t.copy_(buf)
+        return t
+
+
+class _Level:
+    pass
+
+
+class SlabSolver:
+    """Nv V(Ndown,Nup) cycles of the reference's MultiGrid() on an M x M grid split into j-slabs.
+
+    Call from every rank of the process group with identical arguments.  With a
+    single rank (no process group) it degenerates to one slab plus the tail."""
+
+    def __init__(self, M, dx, coarsest=2, schedule=_lib.SCHEDULE_DEFAULT, backend=None, group=None, tail_m=2049,
+                 halo=8):
+        self.be = backend if backend is not None else HipBackend(schedule)
+        self.comm = _Comm(group)
+        self.M, self.dx, self.coarsest = M, dx, coarsest
+        if M < 3 or M % 2 == 0:
+            raise ValueError("Error: Input has even rows and columns!")  # main.cpp:415
+        L = _lib.load()
+        self.depth = L.mgx_depth(M, coarsest)  # main.cpp:286
+        if self.depth < 0:
+            raise ValueError("depth %d < 0" % self.depth)
+        dims = [M]
+        hs = [dx]
+        for _ in range(self.depth):
+            dims.append((dims[-1] - 1) // 2 + 1)  # main.cpp:293
+            hs.append(hs[-1] * 2.0)               # main.cpp:297
+            if dims[-1] < 3 or dims[-1] % 2 == 0:
+                raise ValueError("level of size %d: the reference indexes out of range there" % dims[-1])
+        self.dims, self.hs = dims, hs
+        R, W = self.comm.size, halo
+        self.W = W
+        # first level of the tail: small enough, and every rank must own >= W columns above it
+        nd = 0
+        while nd < self.depth and dims[nd] > tail_m and (dims[nd + 1] - 2) // R >= max(W, 1):
+            nd += 1
+        if nd == 0:
+            raise ValueError("grid %d is not split over %d rank(s) with tail_m=%d: solve it with "
+                             "multigrid_amd.MultiGrid on one GPU" % (M, R, tail_m))
+        self.ndist = nd
+        self.levels = []
+        if nd > 0:
+            mt = dims[nd]
+            b = [0] + [1 + (g * (mt - 2)) // R for g in range(1, R)] + [mt]  # ownership on the tail's finest level
+            bounds = {nd: b}
+            for l in range(nd - 1, -1, -1):
+                bc = bounds[l + 1]
+                bounds[l] = [0] + [2 * bc[g] - 1 for g in range(1, R)] + [dims[l]]
+            self.bounds = bounds
+            g = self.comm.rank
+            for l in range(nd):
+                Lv = _Level()
+                Lv.m, Lv.dx = dims[l], hs[l]
+                Lv.b0, Lv.b1 = bounds[l][g], bounds[l][g + 1]
+                Lv.lo, Lv.hi = max(0, Lv.b0 - W), min(dims[l], Lv.b1 + W)
+                Lv.ncols = Lv.hi - Lv.lo
+                Lv.o0, Lv.o1 = Lv.b0 - Lv.lo, Lv.b1 - Lv.lo              # owned, local
+                Lv.jlo, Lv.jhi = max(Lv.b0, 1) - Lv.lo, min(Lv.b1, dims[l] - 1) - Lv.lo  # produced, local
+                Lv.jfix_lo = 0 if Lv.lo == 0 else -1
+                Lv.jfix_hi = Lv.ncols - 1 if Lv.hi == dims[l] else -1
+                if Lv.b1 - Lv.b0 < W and R > 1:
+                    raise ValueError("rank %d owns %d < %d columns of level %d" % (g, Lv.b1 - Lv.b0, W, l))
+                Lv.f = self.be.zeros(Lv.ncols, Lv.m)
+                Lv.v = [self.be.zeros(Lv.ncols, Lv.m), self.be.zeros(Lv.ncols, Lv.m)]
+                Lv.cur = 0
+                self.levels.append(Lv)
+            # the tail's finest level: produced coarse columns of this rank, padded to a common count
+            self.tail_b = bounds[nd]
+            self.tail_pad = max(bounds[nd][k + 1] - bounds[nd][k] for k in range(R))
+            self.tail_send = self.be.zeros(self.tail_pad, dims[nd])
+            self.tail_f = self.be.zeros(dims[nd], dims[nd])
+        self.tail = self.be.make_tail(dims[nd], hs[nd], coarsest)
+        self._prof = False
+
+    # ---- data in / out ---------------------------------------------------------
+    def set_problem(self, f_global, v_global):
+        """f, v: numpy M x M arrays indexed [i, j]; every rank passes the same arrays
+        (only its own columns are used)."""
+        f_global = np.asarray(f_global, dtype=np.float64)
+        v_global = np.asarray(v_global, dtype=np.float64)
+        L0 = self.levels[0]
+        L0.f = self.be.from_numpy(np.ascontiguousarray(f_global[:, L0.lo:L0.hi].T))
+        L0.v = [self.be.from_numpy(np.ascontiguousarray(v_global[:, L0.lo:L0.hi].T)) for _ in range(2)]
+        L0.cur = 0
+
+    def set_random_rhs(self):
+        """Benchmark input: the splitmix64 random right-hand side, zero guess, generated
+        directly on each GPU for its own columns."""
+        from . import rhs
+        L0 = self.levels[0]
+        L0.f = rhs.random_torch_cols(self.M, L0.lo, L0.hi, device=self.be.device)
+        L0.v = [self.be.zeros(L0.ncols, L0.m), self.be.zeros(L0.ncols, L0.m)]
+        L0.cur = 0
+
+    def owned_solution(self):
+        """(first global column, array [i, j]) of the columns this rank owns."""
+        L0 = self.levels[0]
+        a = self.be.to_numpy(L0.v[L0.cur][L0.o0:L0.o1])
+        return L0.b0, np.asfortranarray(a.T)
+
+    def gather_solution(self):
+        """The full M x M solution on every rank (test helper; moves the whole grid)."""
+        L0 = self.levels[0]
+        R = self.comm.size
+        width = max(self.bounds[0][k + 1] - self.bounds[0][k] for k in range(R))
+        pad = self.be.zeros(width, L0.m)
+        pad[:L0.o1 - L0.o0] = L0.v[L0.cur][L0.o0:L0.o1]
+        allc = self.be.to_numpy(self.comm.allgather(self.be.comm_tensor(pad)))
+        out = np.empty((self.M, self.M), order="F")
+        for k in range(R):
+            a, b = self.bounds[0][k], self.bounds[0][k + 1]
+            out[:, a:b] = allc[k * width:k * width + (b - a)].T
+        return out
+
+    # ---- profiling hooks (same surface as solver.Plan) -----------------------------
+    def profile(self, enable=True):
+        self._prof = bool(enable)
+        self._prof_recs = []
+        self._prof_tot = {}
+
+    def profile_totals(self):
+        for name, a, b in getattr(self, "_prof_recs", []):
+            c, ms = self._prof_tot.get(name, (0, 0.0))
+            self._prof_tot[name] = (c + 1, ms + a.elapsed_time(b))
+        self._prof_recs = []
+        return dict(getattr(self, "_prof_tot", {}))
+
+    def _launch(self, level, name, op):
+        if self._prof and level == 0 and self.be.name == "hip":
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self.be.launch(op)
+            b.record()
+            self._prof_recs.append((name, a, b))
+        else:
+            self.be.launch(op)
+
+    # ---- the cycle -------------------------------------------------------------------
+    def _chain(self, level, name, Lv, pro, ns, res, zero_in, **kw):
+        """[pro] -> ns sweeps -> [res] as launches of at most SLAB_MAX_SWEEPS sweeps."""
+        remaining, first = ns, True
+        while True:
+            k = min(remaining, _lib.SLAB_MAX_SWEEPS)
+            remaining -= k
+            last = remaining == 0
+            pr = pro if first else 0
+            rs = res if last else 0
+            zi = zero_in if first else 0
+            if k > 0 or pr or rs:
+                op = SlabOp(pro=pr, nsweeps=k, res=rs, zero_in=zi, v_in=Lv.v[Lv.cur], v_out=Lv.v[Lv.cur ^ 1], f=Lv.f,
+                            m=Lv.m, ncols=Lv.ncols, jlo=Lv.jlo, jhi=Lv.jhi, jfix_lo=Lv.jfix_lo, jfix_hi=Lv.jfix_hi,
+                            gf0=Lv.lo, dx=Lv.dx, omega=kw["omega"],
+                            coarse_v=kw.get("coarse_v") if pr else None,
+                            coarse_f=kw.get("coarse_f") if rs == 1 else None,
+                            norm_slot=kw.get("norm_slot") if rs == 2 else None,
+                            mc=kw.get("mc"), nccols=kw.get("nccols"), gc0=kw.get("gc0", 0))
+                self._launch(level, name, op)
+                if k > 0 or pr:
+                    Lv.cur ^= 1
+                    if not last:
+                        # the next launch of the chain reads halo columns of what this one wrote
+                        self._exchange_v(Lv)
+            first = False
+            if remaining <= 0:
+                break
+
+    def _halo_ranges(self, Lv):
+        W = self.W
+        s_lo = (Lv.o0, Lv.o0 + W) if Lv.lo > 0 else None            # my first W owned columns -> rank-1
+        r_lo = (Lv.o0 - W, Lv.o0) if Lv.lo > 0 else None            # rank-1's last W owned columns
+        s_hi = (Lv.o1 - W, Lv.o1) if Lv.hi < Lv.m else None
+        r_hi = (Lv.o1, Lv.o1 + W) if Lv.hi < Lv.m else None
+        return s_lo, r_lo, s_hi, r_hi
+
+    def _exchange_v(self, Lv):
+        self.comm.exchange([(self.be.comm_tensor(Lv.v[Lv.cur]),) + self._halo_ranges(Lv)])
+
+    def _coarse_of(self, l):
+        """(coarse f array, coarse v getter, mc, nccols, gc0) of distributed level l."""
+        if l + 1 < self.ndist:
+            C = self.levels[l + 1]
+            return C, C.m, C.ncols, C.lo
+        return None, self.dims[self.ndist], self.dims[self.ndist], 0
+
+    def _vcycle(self, Ndown, Nup, omega, norm_slot):
+        nd = self.ndist
+        for l in range(nd):  # main.cpp:317-328
+            Lv = self.levels[l]
+            C, mc, nccols, gc0 = self._coarse_of(l)
+            cf = C.f if C is not None else self.tail_f
+            zero_in = 1 if (l >= 1 and Ndown >= 1) else 0
+            self._chain(l, "k_stream:down", Lv, 0, Ndown, 1, zero_in, omega=omega, coarse_f=cf, mc=mc, nccols=nccols,
+                        gc0=gc0)
+            items = [(self.be.comm_tensor(Lv.v[Lv.cur]),) + self._halo_ranges(Lv)]
+            if C is not None:
+                items.append((self.be.comm_tensor(C.f),) + self._halo_ranges(C))
+            self.comm.exchange(items)
+        # the tail: all-gather its right-hand side, run it on every rank
+        R, g = self.comm.size, self.comm.rank
+        tb = self.tail_b
+        mt = self.dims[nd]
+        if R > 1:
+            n_own = tb[g + 1] - tb[g]
+            self.tail_send[:n_own] = self.tail_f[tb[g]:tb[g + 1]]
+            allc = self.comm.allgather(self.be.comm_tensor(self.tail_send))
+            for k in range(R):
+                if k != g:
+                    self.tail_f[tb[k]:tb[k + 1]] = allc[k * self.tail_pad:k * self.tail_pad + (tb[k + 1] - tb[k])]
+        vt = self.tail.run(self.tail_f, Ndown, Nup, omega)
+        del mt
+        for l in range(nd - 1, -1, -1):  # main.cpp:335-346
+            Lv = self.levels[l]
+            C, mc, nccols, gc0 = self._coarse_of(l)
+            cv = C.v[C.cur] if C is not None else vt
+            res = 2 if (l == 0 and norm_slot is not None) else 0
+            self._chain(l, "k_stream:up", Lv, 1, Nup, res, 0, omega=omega, coarse_v=cv, norm_slot=norm_slot, mc=mc,
+                        nccols=nccols, gc0=gc0)
+            self._exchange_v(Lv)
+            if Ndown == 0 and C is not None:  # main.cpp:345 (otherwise the next down leg ignores the coarse iterate)
+                C.v[C.cur][:] = 0.0
+
+    def cycles(self, Nv, Ndown, Nup, omega, pureJacobi=False):
+        """Nv cycles (main.cpp:309-354).  Returns MGOutputs; Times is the cumulative wall
+        time of the cycles on this rank (a host clock: exchanges are part of a cycle)."""
+        import time
+        be = self.be
+        slots = be.slots(Nv + 1)
+        L0 = self.levels[0]
+        # main.cpp:307: the norm of the initial residual (halo columns of v must be current)
+        self._exchange_v(L0)
+        self._chain(0, "k_stream:norm", L0, 0, 0, 2, 0, omega=omega, norm_slot=be.slot_ptr(slots, 0))
+        times = np.zeros(Nv + 1)
+        for it in range(Nv):
+            t0 = time.perf_counter()
+            if not pureJacobi:
+                self._vcycle(Ndown, Nup, omega, be.slot_ptr(slots, it + 1))
+            else:  # main.cpp:348 and :351 in one pass
+                self._chain(0, "k_stream:up", L0, 0, 1, 2, 0, omega=omega, norm_slot=be.slot_ptr(slots, it + 1))
+                self._exchange_v(L0)
+            times[it + 1] = times[it] + (time.perf_counter() - t0)
+        self.comm.allreduce_max_(slots)
+        be.synchronize()
+        return MGOutputs(be.decode_slots(slots), times)
+
+    def close(self):
+        if self.tail is not None:
+            self.tail.close()
+            self.tail = None

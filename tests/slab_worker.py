@@ -1,0 +1,76 @@
+"""One rank of a multi-process SlabSolver test (launched by test_slab_cpu.py and
+test_gpu_slab.py with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set).
+
+  python slab_worker.py <backend: numpy|hip> <M> <Nv> <Ndown> <Nup> <omega> <tail_m> <pure_jacobi>
+
+Every rank builds the same global problem, solves it with the slab driver over
+gloo and compares the gathered solution and the residual history with the CPU
+oracle bit for bit.  Exit code 0 = identical.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    backend, M, Nv, nd, nu, omega, tail_m, pure = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]),
+                                                   int(sys.argv[5]), float(sys.argv[6]), int(sys.argv[7]),
+                                                   int(sys.argv[8]))
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    rank = dist.get_rank() if world > 1 else 0
+
+    from oracle import oracle as O
+    from multigrid_amd import rhs, slab
+    if backend == "numpy":
+        from slab_numpy_backend import NumpyBackend
+        be = NumpyBackend(O)
+    else:
+        torch.cuda.set_device(0)  # every rank shares the one GPU of the test box
+        be = slab.HipBackend()
+
+    dx = 1.0 / (M - 1)
+    f = rhs.random_np(M)
+    rng = np.random.default_rng(M)
+    v0 = np.zeros((M, M), order="F")
+    v0[0, :], v0[-1, :], v0[:, 0], v0[:, -1] = rng.standard_normal((4, M))   # non-zero Dirichlet data
+    v0[1:-1, 1:-1] = rng.standard_normal((M - 2, M - 2)) * 0.01              # and a non-zero guess
+
+    S = slab.SlabSolver(M, dx, 2, backend=be, tail_m=tail_m, halo=8)
+    S.set_problem(f, v0)
+    out = S.cycles(Nv, nd, nu, omega, pureJacobi=bool(pure))
+    sol = S.gather_solution()
+    S.close()
+
+    ok = True
+    if rank == 0:
+        ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, 2, pure_jacobi=bool(pure))
+        same_rn = np.array_equal(out.ResidualNorms.view(np.uint64), ref_rn.view(np.uint64))
+        same_sol = np.array_equal(np.ascontiguousarray(sol).view(np.uint64),
+                                  np.ascontiguousarray(ref_sol).view(np.uint64))
+        ok = same_rn and same_sol
+        print("slab_worker: world=%d backend=%s M=%d ndist=%d resnorms_equal=%s sol_equal=%s"
+              % (world, backend, M, S.ndist, same_rn, same_sol), flush=True)
+        if not same_rn:
+            print(out.ResidualNorms, ref_rn, flush=True)
+        if not same_sol:
+            bad = np.argwhere(sol != ref_sol)
+            print("first mismatches [i, j]:", bad[:5].tolist(), "of", len(bad), flush=True)
+    if world > 1:
+        flag = torch.tensor([0 if ok else 1])
+        dist.all_reduce(flag)
+        ok = int(flag.item()) == 0
+        dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""GPU tests of the multi-rank slab path with the HIP backend: one process with
+a single slab, and 2-3 processes that share the test box's one GPU and exchange
+halos over gloo (RCCL needs one GPU per rank, which the test box does not have;
+the launch sequence, ownership and kernels are the same)."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits
+from test_slab_cpu import run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,tail_m,nd,nu", [(257, 33, 2, 2), (513, 65, 2, 2), (257, 33, 5, 6), (257, 65, 0, 2),
+                                            (257, 65, 3, 0), (1025, 129, 2, 2)])
+def test_single_slab_hip_matches_oracle(mg, O, M, tail_m, nd, nu):
+    from multigrid_amd import rhs, slab
+    dx = 1.0 / (M - 1)
+    f = rhs.random_np(M)
+    rng = np.random.default_rng(M)
+    v0 = np.zeros((M, M), order="F")
+    v0[0, :], v0[-1, :], v0[:, 0], v0[:, -1] = rng.standard_normal((4, M))
+    S = slab.SlabSolver(M, dx, 2, tail_m=tail_m)
+    S.set_problem(f, v0)
+    out = S.cycles(3, nd, nu, 0.6)
+    sol = S.gather_solution()
+    S.close()
+    ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, 3, nd, nu, 0.6, 2)
+    assert_bits(out.ResidualNorms, ref_rn, "ResNorms")
+    assert_bits(sol, ref_sol, "Sol")
+
+
+def test_slab_random_rhs_generator(mg):
+    from multigrid_amd import rhs
+    full = rhs.random_np(129)
+    part = rhs.random_torch_cols(129, 40, 77).cpu().numpy()
+    assert_bits(part, np.ascontiguousarray(full[:, 40:77].T), "random_torch_cols")
+    edge = rhs.random_torch_cols(129, 0, 129).cpu().numpy()
+    assert_bits(edge, np.ascontiguousarray(full.T), "random_torch_cols full")
+
+
+@pytest.mark.parametrize("world,M,tail_m", [(2, 513, 65), (3, 1025, 129), (4, 2049, 257)])
+def test_ranks_share_gpu_over_gloo(O, world, M, tail_m):
+    codes, outs = run_ranks(world, ["hip", M, 3, 2, 2, 0.6, tail_m, 0], timeout=400)
+    assert codes == [0] * world, "\n".join(outs)
+    assert "resnorms_equal=True sol_equal=True" in outs[0]
+
+
+def test_slab_launch_rejects_missing_halo(mg):
+    import ctypes
+    from multigrid_amd import _lib
+    L = _lib.load()
+    t = mg.colmajor(65, 20)
+    o = _lib.mgx_slab_op()
+    o.struct_size = ctypes.sizeof(_lib.mgx_slab_op)
+    o.pro, o.nsweeps, o.res, o.zero_in = 0, 2, 0, 0
+    o.v_in, o.v_out, o.f = t.data_ptr(), mg.colmajor(65, 20).data_ptr(), t.data_ptr()
+    o.m, o.ld, o.ncols = 65, 65, 20
+    o.jlo, o.jhi, o.jfix_lo, o.jfix_hi = 1, 19, -1, -1   # needs 2 halo columns on each side, has 1
+    o.dx, o.omega = 0.1, 0.6
+    assert L.mgx_slab_launch(ctypes.byref(o), None) == -1
+    assert b"halo columns needed" in L.mgx_last_error()
+    o.jlo, o.jhi = 2, 18
+    assert L.mgx_slab_launch(ctypes.byref(o), None) == 0

@@ -1,0 +1,106 @@
+"""CPU tests of the multi-rank slab driver (multigrid_amd/slab.py) under gloo:
+ownership, halo exchange, tail all-gather and norm reduction, with the
+arithmetic supplied by a numpy backend that lives in tests/.  The assembled
+solution and the residual history must equal the single-process oracle's bit
+for bit for every world size."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_bits
+
+WORKER = os.path.join(ROOT, "tests", "slab_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(world, args, timeout=300, extra_env=None):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, WORKER] + [str(a) for a in args], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    codes = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+        codes.append(p.returncode)
+    return codes, outs
+
+
+def test_numpy_backend_single_slab_matches_oracle(O):
+    """One rank, no process group: the slab driver + numpy backend alone."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from slab_numpy_backend import NumpyBackend
+    from multigrid_amd import rhs, slab
+    M = 65
+    dx = 1.0 / (M - 1)
+    f = rhs.random_np(M)
+    v0 = np.zeros((M, M), order="F")
+    for (nd, nu, Nv) in [(2, 2, 3), (1, 3, 2), (0, 2, 2), (2, 0, 2), (5, 6, 2)]:
+        S = slab.SlabSolver(M, dx, 2, backend=NumpyBackend(O), tail_m=17, halo=8)
+        assert S.ndist == 2
+        S.set_problem(f, v0)
+        out = S.cycles(Nv, nd, nu, 0.6)
+        sol = S.gather_solution()
+        ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, 0.6, 2)
+        assert_bits(out.ResidualNorms, ref_rn, "ResNorms V(%d,%d)" % (nd, nu))
+        assert_bits(sol, ref_sol, "Sol V(%d,%d)" % (nd, nu))
+
+
+@pytest.mark.parametrize("world,M,tail_m", [(2, 129, 33), (3, 257, 33), (4, 257, 65), (2, 65, 33)])
+def test_gloo_ranks_match_oracle(O, world, M, tail_m):
+    codes, outs = run_ranks(world, ["numpy", M, 3, 2, 2, 0.6, tail_m, 0])
+    assert codes == [0] * world, "\n".join(outs)
+    assert "resnorms_equal=True sol_equal=True" in outs[0]
+
+
+def test_gloo_other_sweep_counts_and_pure_jacobi(O):
+    for args in (["numpy", 129, 2, 5, 6, 0.8, 33, 0], ["numpy", 129, 2, 0, 2, 0.6, 33, 0],
+                 ["numpy", 129, 3, 2, 2, 0.6, 33, 1]):
+        codes, outs = run_ranks(2, args)
+        assert codes == [0, 0], "\n".join(outs)
+
+
+def test_ownership_is_nested_and_covers_every_level(O):
+    from multigrid_amd import slab
+
+    class FakeComm:
+        pass
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from slab_numpy_backend import NumpyBackend
+    S = slab.SlabSolver(1025, 1.0 / 1024, 2, backend=NumpyBackend(O), tail_m=129, halo=8)
+    assert S.ndist == 3 and S.dims[S.ndist] == 129
+    # emulate 8 ranks' bounds with the same rule
+    R = 8
+    mt = S.dims[S.ndist]
+    b = [0] + [1 + (g * (mt - 2)) // R for g in range(1, R)] + [mt]
+    for l in range(S.ndist - 1, -1, -1):
+        fine = [0] + [2 * b[g] - 1 for g in range(1, R)] + [S.dims[l]]
+        for g in range(R):
+            # the rank that owns fine column 2J owns coarse column J
+            for J in range(b[g], b[g + 1]):
+                assert fine[g] <= 2 * J < fine[g + 1] or J == 0 and g == 0
+            assert fine[g + 1] - fine[g] >= 8
+        b = fine
+    S.close()
