@@ -45,17 +45,23 @@ def algorithmic_bytes_per_point(kernel, nd, nu):
         "k_stream:down": 24.0 * nd + 18.0,
         "k_stream:up": 18.0 + 24.0 * nu + 16.0,  # the level-0 up launch also yields the residual norm
         "k_stream:norm": 16.0,
+        # level 0: the up leg of one cycle and the down leg of the next in one launch
+        "k_stream:updown": (18.0 + 24.0 * nu + 16.0) + (24.0 * nd + 18.0),
     }[kernel]
 
 
 def rocprof_kernel_name(kernel, nd, nu):
-    """The name the fine-level launch carries in a rocprofv3 kernel trace."""
+    """The name the fine-level launch carries in a rocprofv3 kernel trace
+    (template arguments NS, PA, NM, RES, ZERO_IN, STORE of k_stream)."""
+    ns = "mgx::(anonymous namespace)::k_stream<%d, %d, %d, %d, false, %s>"
     if kernel == "k_stream:down":
-        return "mgx::(anonymous namespace)::k_stream<false, %d, 1, false>" % nd
+        return ns % (nd, -1, -1, 1, "true" if nd > 0 else "false")
     if kernel == "k_stream:up":
-        return "mgx::(anonymous namespace)::k_stream<true, %d, 2, false>" % nu
+        return ns % (nu, 0, nu, 0, "true")
+    if kernel == "k_stream:updown":
+        return ns % (nu + nd, 0, nu, 1, "true")
     if kernel == "k_stream:norm":
-        return "mgx::(anonymous namespace)::k_stream<false, 0, 2, false>"
+        return ns % (0, -1, 0, 0, "false")
     return "mgx::" + kernel
 
 

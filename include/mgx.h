@@ -136,7 +136,8 @@ int mgx_plan_cycles(mgx_plan *plan, int Nv, int Ndown, int Nup, double omega, in
 #define MGX_KERNEL_RESNORM 4
 #define MGX_KERNEL_FUSED_DOWN 5
 #define MGX_KERNEL_FUSED_UP 6
-#define MGX_KERNEL_COUNT 7
+#define MGX_KERNEL_FUSED_UPDOWN 7 /* level 0: up leg of a cycle + down leg of the next */
+#define MGX_KERNEL_COUNT 8
 int mgx_plan_profile(mgx_plan *plan, int enable);
 int mgx_plan_profile_get(const mgx_plan *plan, int kernel_id, long *count, double *total_ms);
 const char *mgx_kernel_name(int kernel_id);

@@ -94,7 +94,7 @@ SIGNATURES = {
     "mgx_residual_norm": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
 }
 
-KERNEL_COUNT = 7
+KERNEL_COUNT = 8
 
 _LIB = None
 

@@ -254,46 +254,133 @@ int stream_chain(mgx_plan *p, int level, int kid, hipStream_t s, int pro, int ns
     return MGX_OK;
 }
 
-// One V(Ndown,Nup) cycle with the fused streaming kernels: per level one
-// launch on the way down (relax + residual + coarsen, main.cpp:321-327) and one
-// on the way up (refine + add + relax, main.cpp:337-344); on level 0 the up
-// launch also produces the residual norm of main.cpp:351 into norm_slot.
-int vcycle_fused(mgx_plan *p, int Ndown, int Nup, double omega, unsigned long long *norm_slot, bool zero0 = false)
+// ---- fused schedule ---------------------------------------------------------
+// "lean" (Ndown + Nup <= STREAM_MAX_SWEEPS, the usual V(1..2,1..2)):
+//   * a level that starts the down sweep from a zero iterate (every level >= 1,
+//     main.cpp:295-299,345) stores nothing on the way down (f -> coarse f) and
+//     its up leg recomputes the Ndown sweeps from f before adding the coarse
+//     correction: 10 + 18 bytes per point instead of 18 + 26;
+//   * on level 0 the up leg of cycle k and the down leg of cycle k+1 are ONE
+//     launch (correction -> Nup sweeps -> norm -> Ndown sweeps -> residual ->
+//     restriction): 28 bytes per point per cycle instead of 52.
+// Otherwise every leg is a chain of launches of at most STREAM_MAX_SWEEPS sweeps.
+struct FusedCtx {
+    int Ndown, Nup;
+    double omega;
+    bool zero0;  // level 0 itself starts from a zero iterate (the tail of a multi-GPU run)
+    bool lean() const { return Ndown + Nup <= STREAM_MAX_SWEEPS; }
+    bool zero_start(int d) const { return d >= 1 || zero0; }
+};
+
+int launch_leg(mgx_plan *p, int d, int kid, const StreamOp &op, const StreamArgs &A)
+{
+    LAUNCH(p, d, kid, launch_stream(op, A, p->stream));
+    return MGX_OK;
+}
+
+// down leg of level d: relax(Ndown) + residual + coarsen (main.cpp:321-327)
+int fused_down(mgx_plan *p, int d, const FusedCtx &cx)
+{
+    Level &L = p->lv[d];
+    Level &C = p->lv[d + 1];
+    StreamArgs A = level_args(L, &C, cx.omega);
+    A.cout = C.f;
+    if (cx.zero_start(d)) {
+        if (cx.lean()) {  // nothing stored: the up leg recomputes these sweeps
+            StreamOp op;
+            op.ns = cx.Ndown;
+            op.res = 1;
+            op.zero_in = 1;
+            op.store = 0;
+            return launch_leg(p, d, MGX_KERNEL_FUSED_DOWN, op, A);
+        }
+        if (cx.Ndown == 0) {  // residual of the zero iterate; nothing to store either
+            StreamOp op;
+            op.res = 1;
+            op.zero_in = 1;
+            op.store = 0;
+            return launch_leg(p, d, MGX_KERNEL_FUSED_DOWN, op, A);
+        }
+        return stream_chain(p, d, MGX_KERNEL_FUSED_DOWN, p->stream, 0, cx.Ndown, 1, 1, A, L.v, L.cur);
+    }
+    return stream_chain(p, d, MGX_KERNEL_FUSED_DOWN, p->stream, 0, cx.Ndown, 1, 0, A, L.v, L.cur);
+}
+
+// up leg of level d: refine + add + relax(Nup) (main.cpp:337-344); with a slot
+// also the residual norm of the result (main.cpp:351); with next_down (level 0,
+// lean) also the down leg of the following cycle.
+int fused_up(mgx_plan *p, int d, const FusedCtx &cx, unsigned long long *slot, bool next_down)
+{
+    Level &L = p->lv[d];
+    Level &C = p->lv[d + 1];
+    StreamArgs A = level_args(L, &C, cx.omega);
+    A.cin = C.v[C.cur];
+    A.slot = slot;
+    if (cx.zero_start(d)) {
+        if (cx.lean()) {  // sweeps from zero recomputed, correction added after Ndown of them
+            StreamOp op;
+            op.ns = cx.Ndown + cx.Nup;
+            op.pa = cx.Ndown;
+            op.nm = slot ? op.ns : -1;
+            op.zero_in = 1;
+            if (slot && cx.Ndown > 0)
+                return fail(MGX_ERR_STATE, "fused_up: no norm on a recomputing leg");
+            A.uout = L.v[0];
+            L.cur = 0;
+            return launch_leg(p, d, MGX_KERNEL_FUSED_UP, op, A);
+        }
+        if (cx.Ndown == 0)  // the iterate is still zero: not read
+            return stream_chain(p, d, MGX_KERNEL_FUSED_UP, p->stream, 1, cx.Nup, slot ? 2 : 0, 1, A, L.v, L.cur);
+    }
+    if (next_down) {
+        A.cout = C.f;
+        StreamOp op;
+        op.ns = cx.Nup + cx.Ndown;
+        op.pa = 0;
+        op.nm = cx.Nup;
+        op.res = 1;
+        A.uin = L.v[L.cur];
+        A.uout = L.v[L.cur ^ 1];
+        L.cur ^= 1;
+        return launch_leg(p, d, MGX_KERNEL_FUSED_UPDOWN, op, A);
+    }
+    return stream_chain(p, d, MGX_KERNEL_FUSED_UP, p->stream, 1, cx.Nup, slot ? 2 : 0, 0, A, L.v, L.cur);
+}
+
+// levels 1..depth-1 down, the coarsest solve, levels depth-1..1 up
+int fused_coarse_legs(mgx_plan *p, const FusedCtx &cx)
 {
     const int depth = p->depth;
-    hipStream_t s = p->stream;
-    for (int d = 0; d < depth; d++) {
-        Level &L = p->lv[d];
-        Level &C = p->lv[d + 1];
-        StreamArgs A = level_args(L, &C, omega);
-        A.cout = C.f;
-        // a coarse level enters the down sweep with v == 0 (main.cpp:295-299,345): not read
-        const int zero_in = ((d >= 1 || zero0) && Ndown >= 1) ? 1 : 0;
-        int rc = stream_chain(p, d, MGX_KERNEL_FUSED_DOWN, s, 0, Ndown, 1, zero_in, A, L.v, L.cur);
+    for (int d = 1; d < depth; d++) {
+        int rc = fused_down(p, d, cx);
         if (rc) return rc;
     }
-    {
-        Level &B = p->lv[depth];
-        if (B.m == 3) {
-            HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, s));
-        } else if (p->verbose) {
-            printf("Error: Direct solver not defined for %dx%d matrices!\n", B.m, B.m);
-        }
+    Level &B = p->lv[depth];
+    if (B.m == 3) {  // main.cpp:331
+        HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, p->stream));
+    } else if (p->verbose) {
+        printf("Error: Direct solver not defined for %dx%d matrices!\n", B.m, B.m);
     }
-    for (int d = depth - 1; d >= 0; d--) {
-        Level &L = p->lv[d];
-        Level &C = p->lv[d + 1];
-        StreamArgs A = level_args(L, &C, omega);
-        A.cin = C.v[C.cur];
-        const int res = (d == 0 && norm_slot) ? 2 : 0;
-        A.slot = norm_slot;
-        int rc = stream_chain(p, d, MGX_KERNEL_FUSED_UP, s, 1, Nup, res, 0, A, L.v, L.cur);
+    for (int d = depth - 1; d >= 1; d--) {
+        int rc = fused_up(p, d, cx, nullptr, false);
         if (rc) return rc;
-        // main.cpp:345.  With Ndown >= 1 the next down sweep does not read the
-        // coarse iterate (zero_in), so the clear is only needed otherwise.
-        if (Ndown == 0) HIP_TRY(hipMemsetAsync(C.v[C.cur], 0, sizeof(double) * C.n(), s));
     }
     return MGX_OK;
+}
+
+// One whole V(Ndown,Nup) cycle (no cross-cycle fusion): used by mgx_plan_vcycle_async.
+int vcycle_fused(mgx_plan *p, int Ndown, int Nup, double omega, unsigned long long *norm_slot, bool zero0 = false)
+{
+    FusedCtx cx{Ndown, Nup, omega, zero0};
+    if (p->depth == 0) {
+        Level &B = p->lv[0];
+        if (B.m == 3) HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, p->stream));
+        return MGX_OK;
+    }
+    int rc = fused_down(p, 0, cx);
+    if (!rc) rc = fused_coarse_legs(p, cx);
+    if (!rc) rc = fused_up(p, 0, cx, (zero0 && cx.lean() && Ndown > 0) ? nullptr : norm_slot, false);
+    return rc;
 }
 
 } // namespace
@@ -447,7 +534,8 @@ int mgx_plan_profile_get(const mgx_plan *p, int kernel_id, long *count, double *
 const char *mgx_kernel_name(int kernel_id)
 {
     static const char *names[MGX_KERNEL_COUNT] = {"k_jacobi", "k_residual", "k_restrict", "k_refine<1>",
-                                                  "k_residual_norm", "k_stream:down", "k_stream:up"};
+                                                  "k_residual_norm", "k_stream:down", "k_stream:up",
+                                                  "k_stream:updown"};
     return (kernel_id >= 0 && kernel_id < MGX_KERNEL_COUNT) ? names[kernel_id] : "";
 }
 
@@ -510,9 +598,17 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
         unsigned long long *slot = p->slots + iter + 1;
         bool norm_done = false;
         if (p->schedule == MGX_SCHEDULE_FUSED) {
-            if (!pure_jacobi) {
+            if (!pure_jacobi && p->depth > 0) {
+                FusedCtx cx{Ndown, Nup, omega, false};
+                // lean: the previous cycle's level-0 launch already did this cycle's down leg
+                const bool lean = cx.lean() && (Ndown + Nup) >= 1;
+                rc = MGX_OK;
+                if (iter == 0 || !lean) rc = fused_down(p, 0, cx);
+                if (!rc) rc = fused_coarse_legs(p, cx);
+                if (!rc) rc = fused_up(p, 0, cx, slot, lean && iter + 1 < Nv);
+                norm_done = true;
+            } else if (!pure_jacobi) {
                 rc = vcycle_fused(p, Ndown, Nup, omega, slot);
-                norm_done = p->depth > 0;
             } else {  // main.cpp:348 with the norm of :351 in the same pass
                 StreamArgs A = level_args(L0, nullptr, omega);
                 A.slot = slot;
@@ -798,8 +894,8 @@ int mgx_plan_vcycle_async(mgx_plan *p, int Ndown, int Nup, double omega, int zer
 {
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_vcycle_async: null plan");
     if (Ndown < 0 || Nup < 0) return fail(MGX_ERR_ARG, "mgx_plan_vcycle_async: negative count");
-    if (zero_guess && !(p->schedule == MGX_SCHEDULE_FUSED && Ndown >= 1)) {
-        // the schedule will read the iterate: make it zero in memory
+    if (zero_guess && p->schedule != MGX_SCHEDULE_FUSED) {
+        // the stepwise schedule reads the iterate: make it zero in memory
         Level &L = p->lv[0];
         HIP_TRY(hipMemsetAsync(L.v[L.cur], 0, sizeof(double) * L.n(), p->stream));
     }

@@ -76,8 +76,32 @@ struct StreamArgs {
     SweepCoef c;
 };
 static constexpr int STREAM_MAX_SWEEPS = 4;
-// pro in {0,1}; ns in 0..STREAM_MAX_SWEEPS; res 0 none, 1 restrict into cout, 2 norm into slot;
-// zero_in: the input iterate is all zeros and is not read (needs ns >= 1, pro == 0).
-hipError_t launch_stream(int pro, int ns, int res, int zero_in, const StreamArgs &A, hipStream_t s);
+// What one launch computes: ns sweeps; the coarse-grid correction added to
+// stage pa (-1: none); the residual norm of stage nm merged into the slot
+// (-1: none); res: the residual of stage ns restricted into cout; zero_in: the
+// input iterate is all zeros and is not read; store: stage ns is written to uout.
+struct StreamOp {
+    int ns = 0, pa = -1, nm = -1, res = 0, zero_in = 0, store = 1;
+};
+hipError_t launch_stream(const StreamOp &op, const StreamArgs &A, hipStream_t s);
+// halo columns (and rows) the pipeline of `op` consumes beyond the produced range
+int stream_halo(const StreamOp &op);
+// The four-flag form of the simple legs: pro in {0,1}; res 0 none, 1 restrict,
+// 2 norm of the result.
+inline StreamOp simple_op(int pro, int ns, int res, int zero_in)
+{
+    StreamOp op;
+    op.ns = ns;
+    op.pa = pro ? 0 : -1;
+    op.nm = res == 2 ? ns : -1;
+    op.res = res == 1 ? 1 : 0;
+    op.zero_in = zero_in;
+    op.store = (ns > 0 || pro) ? 1 : 0;
+    return op;
+}
+inline hipError_t launch_stream(int pro, int ns, int res, int zero_in, const StreamArgs &A, hipStream_t s)
+{
+    return launch_stream(simple_op(pro, ns, res, zero_in), A, s);
+}
 
 } // namespace mgx

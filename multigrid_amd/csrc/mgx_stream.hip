@@ -1,36 +1,42 @@
 // mgx_stream.hip -- fused streaming kernels for gfx950.
 //
-// One kernel template covers every fused step of the V-cycle:
+// One kernel template covers every fused step of the V-cycle.  A launch is a
+// pipeline over the NS+1 "stages" of the iterate (stage 0 = the input, stage s
+// = after s damped-Jacobi sweeps, reference relax(), main.cpp:171-199):
 //
-//   k_stream<PRO, NS, RES, ZERO_IN>
-//     PRO      1: stage 0 is v + P(coarse v)   (refine + `cur += refined`,
-//                 reference main.cpp:339-341)
-//     NS       number of damped-Jacobi sweeps applied in registers
-//                 (relax, main.cpp:171-199)
-//     RES      1: residual of the result, restricted into the coarse f
-//                 (residual + coarsen, main.cpp:325-327)
-//              2: residual of the result reduced to its infinity norm
-//                 (calcNorm(residual), main.cpp:351)
-//     ZERO_IN  1: the input iterate is known to be all zeros and is not read
-//                 (a coarse level at the start of the down sweep, main.cpp:345)
+//   k_stream<NS, PA, NM, RES, ZERO_IN, STORE>
+//     NS       number of sweeps applied in registers
+//     PA       >= 0: the coarse-grid correction P(coarse v) is added to stage PA
+//              (refine + `cur += refined`, main.cpp:339-341); -1: none
+//     NM       >= 0: the infinity norm of the residual of stage NM is merged into
+//              a slot (calcNorm(residual), main.cpp:307,351); -1: none
+//     RES      1: the residual of stage NS is restricted into the coarse f
+//              (residual + coarsen, main.cpp:325-327)
+//     ZERO_IN  the input iterate is all zeros and is not read (a coarse level
+//              when the down sweep reaches it, main.cpp:295-299,345)
+//     STORE    stage NS is written to the output iterate
 //
-// so "down" = <0,nu1,1,*> reads v,f once and writes v and the coarse f, and
-// "up" = <1,nu2,0|2,0> reads the coarse v, v, f once and writes v: 26 B per
-// fine point each instead of the 66 B the separate operators move.
+// The legs of a cycle are instances of it:
+//   down            <nu1,-1,-1,1,*,*>       relax + residual + coarsen
+//   up              <nu2, 0,-1|nu2,0,0,1>   refine + add + relax (+ norm on level 0)
+//   up+down         <nu2+nu1,0,nu2,1,0,1>   level 0: the up leg of cycle k and the
+//                                           down leg of cycle k+1 in ONE pass
+//   recomputing up  <nu1+nu2,nu1,-1,0,1,1>  levels >= 1: the down sweeps started
+//                                           from zero, so they are recomputed from
+//                                           f instead of being stored and re-read
 //
 // Mapping.  A wavefront owns a strip of 128 consecutive rows i (lane t holds
 // rows r0+2t and r0+2t+1 in registers) and marches along the columns j of a
 // chunk.  Column j of the input is loaded once (coalesced: the 64 lanes read
-// 1 KiB of one column, 16 B per lane); sweep s of column j-s is computed as
-// soon as sweep s-1 of columns j-s-1..j-s+1 exists, so the NS sweeps, the
-// residual and the restriction form a software pipeline that lags the load
-// front by NS+2 columns and never touches memory in between.  North/south
-// neighbours (j-1, j+1) are the lane's own registers of the previous/next
-// column; west/east neighbours (i-1, i+1) are the lane's other row or one
-// cross-lane shift.  Waves are independent: no LDS, no barriers.  Strips
-// overlap by the halo the pipeline consumes (NS+2 rows below, NS+1 above),
-// chunks by the same number of columns; the overlap is recomputed, not
-// communicated.
+// 1 KiB of one column, 16 B per lane); stage s of column j-s is computed as
+// soon as stage s-1 of columns j-s-1..j-s+1 exists, so the sweeps, the residual
+// and the restriction form a software pipeline that lags the load front by
+// NS+2 columns and never touches memory in between.  North/south neighbours
+// (j-1, j+1) are the lane's own registers of the previous/next column;
+// west/east neighbours (i-1, i+1) are the lane's other row or one cross-lane
+// shift.  Waves are independent: no LDS, no barriers.  Strips overlap by the
+// halo the pipeline consumes (NS+2 rows below, NS+1 above), chunks by the same
+// number of columns; the overlap is recomputed, not communicated.
 //
 // The march is unrolled by two so that the parity of the column (which decides
 // the interpolation formula and when a coarse column is complete) is static,
@@ -53,17 +59,18 @@ struct P2 {
     double a, b;  // rows ra (even offset in the strip) and ra+1
 };
 
-template <bool PRO, int NS, int RES>
+template <int NS, int PA, int NM, int RES>
 struct Geo {
+    static constexpr bool RESID_END = (RES != 0) || (NM == NS);  // a residual of stage NS is taken
     // rows of halo the pipeline consumes below / above the rows a strip owns
-    static constexpr int HL = NS + (RES == 1 ? 2 : RES == 2 ? 1 : 0);
-    static constexpr int HH = NS + (RES >= 1 ? 1 : 0) + (PRO ? 1 : 0);
+    static constexpr int HL = NS + (RES ? 2 : (NM == NS ? 1 : 0));
+    static constexpr int HH = NS + (RESID_END ? 1 : 0) + (PA == 0 ? 1 : 0);
     static constexpr int PADLO = (HL + 1) & ~1;            // even, so that r0 is even
     static constexpr int S = (128 - PADLO - HH) & ~1;      // rows owned per strip (even)
     // columns of halo a chunk consumes before its first owned column
     static constexpr int HLC = HL;
     // last input column the march must reach, relative to the chunk end jb
-    static constexpr int JLAST = NS + (RES == 1 ? 1 : RES == 2 ? 0 : -1);
+    static constexpr int JLAST = NS + (RES ? 1 : (NM == NS ? 0 : -1));
 };
 
 __device__ __forceinline__ double jacobi_pt(double uW, double uE, double uS, double uN, double uC, double f,
@@ -94,10 +101,12 @@ __device__ __forceinline__ double from_upper_lane(double v) { return __shfl_down
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-template <bool PRO, int NS, int RES, bool ZERO_IN, bool EDGE>
+template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE, bool EDGE>
 __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip, const int chunk)
 {
-    using G = Geo<PRO, NS, RES>;
+    using G = Geo<NS, PA, NM, RES>;
+    constexpr bool PRO = PA >= 0;
+    constexpr bool NORM = NM >= 0;
     constexpr int PF = 2;  // columns of load-ahead
     const int lane = threadIdx.x & 63;
     const int m = A.m;
@@ -154,17 +163,25 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
     };
 
     // ---- prolongation state (PRO) -------------------------------------------
-    // coarse row of this lane: I = ra/2 (ra is even); its upper neighbour I+1
-    // comes from lane t+1.
+    // The correction is added to stage PA, whose newest column at input column
+    // jin is jin-PA.  Coarse row of this lane: I = ra/2 (ra is even); its upper
+    // neighbour I+1 comes from lane t+1.
     const int I = ra >> 1;
     const int I_c = EDGE ? clampi(I, 0, A.mc - 1) : I;
     const double *__restrict__ pc = PRO ? (A.cin + I_c) : nullptr;
     auto load_c = [&](int J) -> double { return pc[(size_t)clampi(J, 0, A.nccols - 1) * (size_t)A.ldc]; };
     double c0 = 0, c0u = 0, c1 = 0, c1u = 0, cnext = 0;  // cols J, J+1 (own row, row I+1) and raw col J+2
-    int Jl = 0;                                          // local coarse column J of the current even column
+    int Jl = 0;                                          // local coarse column J of the current column pair
     if (PRO) {
-        // primed one column back: the first (even) step rotates into place
-        Jl = ((jstart + A.gf0) >> 1) - A.gc0 - 1;
+        // state as it stands just before the first corrected column g0 = jstart-PA
+        // (global index): an even column rotates first, an odd one does not
+        const int g0 = jstart - PA + A.gf0;
+        const bool g0odd = (g0 & 1) != 0;
+        Jl = (g0 >> 1) - A.gc0 - (g0odd ? 0 : 1);
+        if (g0odd) {
+            c0 = load_c(Jl);
+            c0u = from_upper_lane(c0);
+        }
         c1 = load_c(Jl + 1);
         cnext = load_c(Jl + 2);
         c1u = from_upper_lane(c1);
@@ -173,7 +190,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
     // ---- pipeline registers ---------------------------------------------------
     P2 U[NS + 1][3];  // U[s][2] = newest column of stage s, [1], [0] the two before it
     P2 Fq[NS + 2];    // Fq[k] = f of column jin-k (k >= 1)
-    P2 R[3];          // residual columns jr-2, jr-1, jr
+    P2 R[3];          // residual columns jr-2, jr-1, jr of stage NS
 #pragma unroll
     for (int s = 0; s <= NS; s++)
 #pragma unroll
@@ -191,11 +208,58 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
         Pf[k] = load_col(pfa, pfb, jstart - 1 + k);
     }
 
-    double nacc = 0.0;  // RES==2: running max |r| (boundary residuals are +0.0)
+    double nacc = 0.0;  // NORM: running max |r| (boundary residuals are +0.0)
 
     // One column step; ODD is the parity of the global column index of jin.
     auto step = [&](const int jin, auto odd_tag) {
         constexpr bool ODD = decltype(odd_tag)::value;
+
+        // P(coarse) added to column jp (parity ODDP) of stage PA
+        auto add_correction = [&](P2 &x, const int jp, auto oddp_tag) {
+            constexpr bool ODDP = decltype(oddp_tag)::value;
+            if (!ODDP) {  // entered a new coarse column
+                Jl += 1;
+                c0 = c1;
+                c0u = c1u;
+                c1 = cnext;
+                c1u = from_upper_lane(c1);
+                cnext = load_c(Jl + 2);
+            }
+            double pa, pb;
+            if (!ODDP) {  // main.cpp:236, :242
+                pa = c0;
+                pb = 0.5 * (c0 + c0u);
+            } else {  // main.cpp:239, :245
+                pa = 0.5 * (c0 + c1);
+                double s4 = c0 + c0u;
+                s4 = s4 + c1;
+                s4 = s4 + c1u;
+                pb = 0.25 * s4;
+            }
+            const bool colfix = (jp == jfl) || (jp == jfh) || jp < 0 || jp >= ncols;
+            const double na = x.a + pa;  // main.cpp:341
+            const double nb = x.b + pb;
+            x.a = (colfix || fixa) ? x.a : na;
+            x.b = (colfix || fixb) ? x.b : nb;
+        };
+        // residual of stage s at column jin-s-1 (its three columns are in U[s])
+        auto residual_col = [&](auto s_tag) -> P2 {
+            constexpr int s = decltype(s_tag)::value;
+            const P2 uS = U[s][0], uC = U[s][1], uN = U[s][2];
+            const double wa = from_lower_lane(uC.b);
+            const double eb = from_upper_lane(uC.a);
+            P2 r;
+            r.a = residual_pt(wa, uC.b, uS.a, uN.a, uC.a, Fq[s + 1].a, c);
+            r.b = residual_pt(uC.a, eb, uS.b, uN.b, uC.b, Fq[s + 1].b, c);
+            return r;
+        };
+        auto norm_merge = [&](const P2 &r, const int jr) {
+            const bool colok = jr >= ja && jr < jb && jr != jfl && jr != jfh;
+            const double xa = __builtin_fabs(r.a), xb = __builtin_fabs(r.b);
+            if (colok && owna) nacc = (nacc < xa) ? xa : nacc;
+            if (colok && ownb) nacc = (nacc < xb) ? xb : nacc;
+        };
+
         // ---- take column jin from the load-ahead queue, refill it ----------
         P2 u0 = Pu[0];
         const P2 f1 = Pf[0];
@@ -207,47 +271,22 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
         if (!ZERO_IN) Pu[PF - 1] = load_col(pua, pub, jin + PF);
         Pf[PF - 1] = load_col(pfa, pfb, jin - 1 + PF);
 
-        // ---- stage 0: the input iterate, plus the coarse-grid correction ------
-        if (PRO) {
-            if (!ODD) {  // entered a new coarse column
-                Jl += 1;
-                c0 = c1;
-                c0u = c1u;
-                c1 = cnext;
-                c1u = from_upper_lane(c1);
-                cnext = load_c(Jl + 2);
-            }
-            double pa, pb;
-            if (!ODD) {  // main.cpp:236, :242
-                pa = c0;
-                pb = 0.5 * (c0 + c0u);
-            } else {  // main.cpp:239, :245
-                pa = 0.5 * (c0 + c1);
-                double s4 = c0 + c0u;
-                s4 = s4 + c1;
-                s4 = s4 + c1u;
-                pb = 0.25 * s4;
-            }
-            const bool colfix = (jin == jfl) || (jin == jfh) || jin < 0 || jin >= ncols;
-            const double na = u0.a + pa;  // main.cpp:341
-            const double nb = u0.b + pb;
-            u0.a = (colfix || fixa) ? u0.a : na;
-            u0.b = (colfix || fixb) ? u0.b : nb;
-        }
+        // ---- stage 0 ---------------------------------------------------------
+        if (PA == 0) add_correction(u0, jin, std::integral_constant<bool, ODD>{});
         U[0][0] = U[0][1];
         U[0][1] = U[0][2];
         U[0][2] = u0;
 #pragma unroll
         for (int k = NS + 1; k > 1; k--) Fq[k] = Fq[k - 1];
         Fq[1] = f1;
-
-        if (NS == 0 && PRO) {  // prolong + correct only: stage 0 is the output
+        if (NS == 0 && PRO && STORE) {  // prolong + correct only: stage 0 is the output
             if (jin >= ja && jin < jb && jin != jfl && jin != jfh) store_col(jin, u0);
         }
+        if (NORM && NM == 0 && NS > 0) norm_merge(residual_col(std::integral_constant<int, 0>{}), jin - 1);
 
         // ---- stages 1..NS: damped Jacobi sweeps ----------------------------------
-#pragma unroll
-        for (int s = 1; s <= NS; s++) {
+        auto sweep = [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
             const int jc = jin - s;
             const P2 uS = U[s - 1][0], uC = U[s - 1][1], uN = U[s - 1][2];
             const bool colfix = (jc == jfl) || (jc == jfh);  // Dirichlet column: untouched by relax
@@ -258,27 +297,25 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
             P2 nw;
             nw.a = (colfix || fixa) ? uC.a : na;
             nw.b = (colfix || fixb) ? uC.b : nb;
+            if (PA == s) add_correction(nw, jc, std::integral_constant<bool, (ODD != ((s & 1) != 0))>{});
             U[s][0] = U[s][1];
             U[s][1] = U[s][2];
             U[s][2] = nw;
-            if (s == NS && jc >= ja && jc < jb && !colfix) store_col(jc, nw);
-        }
+            if (s == NS && STORE && jc >= ja && jc < jb && !colfix) store_col(jc, nw);
+            if (NORM && NM == s && s < NS) norm_merge(residual_col(std::integral_constant<int, s>{}), jc - 1);
+        };
+        if constexpr (NS >= 1) sweep(std::integral_constant<int, 1>{});
+        if constexpr (NS >= 2) sweep(std::integral_constant<int, 2>{});
+        if constexpr (NS >= 3) sweep(std::integral_constant<int, 3>{});
+        if constexpr (NS >= 4) sweep(std::integral_constant<int, 4>{});
+        static_assert(NS <= 4, "at most 4 sweeps per launch");
 
-        // ---- residual of stage NS at column jr ------------------------------------
-        if (RES != 0) {
+        // ---- residual of stage NS at column jr -----------------------------------
+        if constexpr (G::RESID_END) {
             const int jr = jin - NS - 1;
-            const P2 uS = U[NS][0], uC = U[NS][1], uN = U[NS][2];
-            const double wa = from_lower_lane(uC.b);
-            const double eb = from_upper_lane(uC.a);
-            P2 r;
-            r.a = residual_pt(wa, uC.b, uS.a, uN.a, uC.a, Fq[NS + 1].a, c);
-            r.b = residual_pt(uC.a, eb, uS.b, uN.b, uC.b, Fq[NS + 1].b, c);
-            if (RES == 2) {
-                const bool colok = jr >= ja && jr < jb && jr != jfl && jr != jfh;
-                const double xa = __builtin_fabs(r.a), xb = __builtin_fabs(r.b);
-                if (colok && owna) nacc = (nacc < xa) ? xa : nacc;
-                if (colok && ownb) nacc = (nacc < xb) ? xb : nacc;
-            } else {
+            const P2 r = residual_col(std::integral_constant<int, NS>{});
+            if (NORM && NM == NS) norm_merge(r, jr);
+            if (RES) {
                 R[0] = R[1];
                 R[1] = R[2];
                 R[2] = r;
@@ -313,7 +350,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
         step(jin + 1, std::true_type{});
     }
 
-    if (RES == 2) {
+    if (NORM) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double o = __shfl_xor(nacc, off, 64);
@@ -323,24 +360,24 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
     }
 }
 
-template <bool PRO, int NS, int RES, bool ZERO_IN>
+template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
 __global__ __launch_bounds__(256) void k_stream(const StreamArgs A)
 {
-    using G = Geo<PRO, NS, RES>;
+    using G = Geo<NS, PA, NM, RES>;
     const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (strip >= A.nstrips) return;
     const int r0 = strip * G::S - G::PADLO;
     const bool edge = (r0 < 1) || (r0 + 127 > A.m - 2);
     if (edge)
-        stream_wave<PRO, NS, RES, ZERO_IN, true>(A, strip, (int)blockIdx.y);
+        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, true>(A, strip, (int)blockIdx.y);
     else
-        stream_wave<PRO, NS, RES, ZERO_IN, false>(A, strip, (int)blockIdx.y);
+        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, false>(A, strip, (int)blockIdx.y);
 }
 
-template <bool PRO, int NS, int RES, bool ZERO_IN>
+template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
 hipError_t launch_one(StreamArgs A, hipStream_t s)
 {
-    using G = Geo<PRO, NS, RES>;
+    using G = Geo<NS, PA, NM, RES>;
     const int m = A.m;
     A.nstrips = (m - 1 + G::S - 1) / G::S;  // strips own rows 0..m-2
     const int ncolsout = A.jhi - A.jlo;
@@ -352,44 +389,63 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
     while (CJ > 16 && (long)nsg * ((ncolsout + CJ - 1) / CJ) < 2048) CJ >>= 1;
     A.CJ = CJ;
     A.nchunks = (ncolsout + CJ - 1) / CJ;
-    hipLaunchKernelGGL((k_stream<PRO, NS, RES, ZERO_IN>), dim3((unsigned)nsg, (unsigned)A.nchunks), dim3(256), 0, s, A);
+    hipLaunchKernelGGL((k_stream<NS, PA, NM, RES, ZERO_IN, STORE>), dim3((unsigned)nsg, (unsigned)A.nchunks),
+                       dim3(256), 0, s, A);
     return hipGetLastError();
-}
-
-template <bool PRO, int RES, bool ZERO_IN>
-hipError_t launch_ns(int ns, const StreamArgs &A, hipStream_t s)
-{
-    switch (ns) {
-    case 0: return launch_one<PRO, 0, RES, ZERO_IN>(A, s);
-    case 1: return launch_one<PRO, 1, RES, ZERO_IN>(A, s);
-    case 2: return launch_one<PRO, 2, RES, ZERO_IN>(A, s);
-    case 3: return launch_one<PRO, 3, RES, ZERO_IN>(A, s);
-    case 4: return launch_one<PRO, 4, RES, ZERO_IN>(A, s);
-    default: return hipErrorInvalidValue;
-    }
 }
 
 } // namespace
 
-hipError_t launch_stream(int pro, int ns, int res, int zero_in, const StreamArgs &A, hipStream_t s)
+int stream_halo(const StreamOp &op)
 {
-    if (ns < 0 || ns > STREAM_MAX_SWEEPS) return hipErrorInvalidValue;
-    if (pro) {
-        if (zero_in) return hipErrorInvalidValue;
-        if (res == 0) return launch_ns<true, 0, false>(ns, A, s);
-        if (res == 2) return launch_ns<true, 2, false>(ns, A, s);
-        return hipErrorInvalidValue;
-    }
-    if (ns == 0 && res == 0) return hipSuccess;  // nothing to do
-    if (zero_in) {
-        if (ns == 0) return hipErrorInvalidValue;
-        if (res == 0) return launch_ns<false, 0, true>(ns, A, s);
-        if (res == 1) return launch_ns<false, 1, true>(ns, A, s);
-        return hipErrorInvalidValue;
-    }
-    if (res == 0) return launch_ns<false, 0, false>(ns, A, s);
-    if (res == 1) return launch_ns<false, 1, false>(ns, A, s);
-    return launch_ns<false, 2, false>(ns, A, s);
+    return op.ns + (op.res ? 2 : (op.nm == op.ns && op.nm >= 0 ? 1 : 0));
+}
+
+// The instances that exist.  Anything else is rejected (hipErrorInvalidValue),
+// and the schedules in mgx_api.hip only compose these.
+hipError_t launch_stream(const StreamOp &op, const StreamArgs &A, hipStream_t s)
+{
+    const int ns = op.ns, pa = op.pa, nm = op.nm, res = op.res;
+    const bool z = op.zero_in != 0, st = op.store != 0;
+#define MGX_TRY(NS, PA, NM, RES, Z, ST)                                                     \
+    if (ns == (NS) && pa == (PA) && nm == (NM) && res == (RES) && z == (Z) && st == (ST))     \
+        return launch_one<NS, PA, NM, RES, Z, ST>(A, s);
+#define MGX_FOR_NS0(M, ...) M(0, __VA_ARGS__) M(1, __VA_ARGS__) M(2, __VA_ARGS__) M(3, __VA_ARGS__) M(4, __VA_ARGS__)
+#define MGX_FOR_NS1(M, ...) M(1, __VA_ARGS__) M(2, __VA_ARGS__) M(3, __VA_ARGS__) M(4, __VA_ARGS__)
+
+    // down leg: sweeps + residual + restriction (input read or known zero; output stored or not)
+#define MGX_DOWN(NS, Z, ST) MGX_TRY(NS, -1, -1, 1, Z, ST)
+    MGX_FOR_NS0(MGX_DOWN, false, true)
+    MGX_DOWN(0, false, false)
+    MGX_FOR_NS1(MGX_DOWN, true, true)
+    MGX_FOR_NS0(MGX_DOWN, true, false)
+    // sweeps only (links of a chain longer than 4 sweeps)
+#define MGX_SWEEP(NS, Z) MGX_TRY(NS, -1, -1, 0, Z, true)
+    MGX_FOR_NS1(MGX_SWEEP, false)
+    MGX_FOR_NS1(MGX_SWEEP, true)
+    // sweeps (or none) + residual norm
+#define MGX_NORM(NS, ST) MGX_TRY(NS, -1, NS, 0, false, ST)
+    MGX_NORM(0, false)
+    MGX_FOR_NS1(MGX_NORM, true)
+    // up leg: correction at stage 0, sweeps, optional norm
+#define MGX_UP(NS, Z) MGX_TRY(NS, 0, -1, 0, Z, true) MGX_TRY(NS, 0, NS, 0, Z, true)
+    MGX_FOR_NS0(MGX_UP, false)
+    MGX_FOR_NS0(MGX_UP, true)
+    // level 0, up leg of one cycle + down leg of the next: correction at stage 0,
+    // norm after nu2 sweeps, restriction after nu2+nu1
+#define MGX_UPDOWN(NS, NM) MGX_TRY(NS, 0, NM, 1, false, true)
+    MGX_UPDOWN(1, 0) MGX_UPDOWN(1, 1)
+    MGX_UPDOWN(2, 0) MGX_UPDOWN(2, 1) MGX_UPDOWN(2, 2)
+    MGX_UPDOWN(3, 0) MGX_UPDOWN(3, 1) MGX_UPDOWN(3, 2) MGX_UPDOWN(3, 3)
+    MGX_UPDOWN(4, 0) MGX_UPDOWN(4, 1) MGX_UPDOWN(4, 2) MGX_UPDOWN(4, 3) MGX_UPDOWN(4, 4)
+    // levels >= 1, up leg that recomputes the nu1 down sweeps from zero: correction at stage nu1
+#define MGX_REUP(NS, PA) MGX_TRY(NS, PA, -1, 0, true, true)
+    MGX_REUP(1, 1)
+    MGX_REUP(2, 1) MGX_REUP(2, 2)
+    MGX_REUP(3, 1) MGX_REUP(3, 2) MGX_REUP(3, 3)
+    MGX_REUP(4, 1) MGX_REUP(4, 2) MGX_REUP(4, 3) MGX_REUP(4, 4)
+#undef MGX_TRY
+    return hipErrorInvalidValue;
 }
 
 } // namespace mgx
