@@ -198,32 +198,42 @@ int mgx_fused_up(const double *coarse_v_dev, double *v_dev, const double *f_dev,
 /* ---- j-slab operator: the unit a multi-GPU driver launches ------------------
  *
  * The reference is single-process; this entry point has no counterpart there.
- * It runs one fused leg ([refine + add] -> nsweeps x relax -> [residual ->
- * coarsen | calcNorm], the operators of main.cpp:171-281) on a SLAB: an m-row
- * column-major array holding `ncols` consecutive columns of a level, i.e. the
- * columns one GPU owns plus the halo columns copied from its neighbours.
+ * It runs one fused leg built from the operators of main.cpp:171-281 on a SLAB:
+ * an m-row column-major array holding `ncols` consecutive columns of a level,
+ * i.e. the columns one GPU owns plus the halo columns copied from its
+ * neighbours.  The leg is a pipeline over the stages of the iterate (stage 0 =
+ * v_in, stage s = after s relax sweeps):
+ *   nsweeps       number of damped-Jacobi sweeps (<= MGX_SLAB_MAX_SWEEPS)
+ *   pro_stage     >= 0: P(coarse_v) (refine) is added to that stage; -1: none
+ *   norm_stage    >= 0: max |residual| of that stage over the produced columns
+ *                 is merged (atomic max) into *norm_slot, encoded as
+ *                 mgx_norm_decode() reads it; -1: none
+ *   restrict_out  1: coarsen(residual(stage nsweeps)) of the produced columns
+ *                 with even global index is written to coarse_f
+ *   zero_in       1: v_in is all zeros and is not read
+ *   store         1: rows 1..m-2 of the produced columns of stage nsweeps are
+ *                 written to v_out (never a Dirichlet column)
+ * The legs that exist (others are rejected with MGX_ERR_ARG):
+ *   down            pro -1, norm -1, restrict 1            (any zero_in/store that makes sense)
+ *   sweeps          pro -1, norm -1, restrict 0, store 1, nsweeps >= 1
+ *   (sweeps +) norm pro -1, norm = nsweeps, restrict 0
+ *   up              pro 0, norm -1 or nsweeps, restrict 0, store 1
+ *   up + down       pro 0, norm 0..nsweeps, restrict 1, store 1, zero_in 0, nsweeps >= 1
+ *   recomputing up  pro 1..nsweeps, norm -1, restrict 0, store 1, zero_in 1
  * Only columns [jlo, jhi) are produced; the columns around them are read as
  * halo.  A slab that contains a physical boundary column (global j = 0 or
  * j = M-1) names its local index in jfix_lo / jfix_hi (else -1); Dirichlet
  * columns are never updated and end the halo requirement on that side.
  * Without a fixed column on a side, the caller must supply, beyond the produced
- * range, nsweeps (+2 on the left, +2 on the right when res == 1; +1 on both
- * sides when res == 2) valid input columns of v_in and f; the call is rejected
- * otherwise.  gf0 / gc0 are the GLOBAL column indices of local column 0 of the
- * fine / coarse slab: global coarse column J pairs with global fine column 2J.
- *   pro      1: stage 0 is v_in + P(coarse_v)
- *   res      0: none; 1: coarsen(residual) of the produced columns with even
- *            global index is written to coarse_f; 2: max |residual| over the
- *            produced columns is merged (atomic max) into *norm_slot, encoded
- *            as mgx_norm_decode() reads it
- *   zero_in  1: v_in is all zeros and is not read (requires nsweeps >= 1, pro 0)
- * v_out receives rows 1..m-2 of the produced columns (never a Dirichlet
- * column) when pro or nsweeps >= 1; v_in and v_out must not overlap.
- * Asynchronous on `stream`; nsweeps <= MGX_SLAB_MAX_SWEEPS per launch. */
+ * range, nsweeps (+2 with restrict_out; +1 with norm_stage == nsweeps) valid
+ * columns of v_in and f, and the coarse columns they interpolate from; the call
+ * is rejected otherwise.  gf0 / gc0 are the GLOBAL column indices of local
+ * column 0 of the fine / coarse slab: global coarse column J pairs with global
+ * fine column 2J.  v_in and v_out must not overlap.  Asynchronous on `stream`. */
 #define MGX_SLAB_MAX_SWEEPS 4
 typedef struct mgx_slab_op {
     int struct_size;
-    int pro, nsweeps, res, zero_in;
+    int nsweeps, pro_stage, norm_stage, restrict_out, zero_in, store;
     const double *v_in;
     double *v_out;
     const double *f;
@@ -231,7 +241,7 @@ typedef struct mgx_slab_op {
     double *coarse_f;
     unsigned long long *norm_slot;
     int m, ld, ncols;       /* fine slab: rows, pitch (>= m), columns present   */
-    int mc, ldc, nccols;    /* coarse slab (pro or res == 1)                    */
+    int mc, ldc, nccols;    /* coarse slab (pro_stage >= 0 or restrict_out)     */
     int jlo, jhi;           /* fine local columns to produce                    */
     int jfix_lo, jfix_hi;   /* local index of Dirichlet columns, or -1          */
     int gf0, gc0;           /* global column index of local column 0            */
@@ -239,7 +249,7 @@ typedef struct mgx_slab_op {
 } mgx_slab_op;
 int mgx_slab_launch(const mgx_slab_op *op, void *stream);
 
-/* Decode a norm slot written with res == 2 (0 decodes to -infinity: nothing
+/* Decode a norm slot written through norm_stage (0 decodes to -infinity: nothing
  * merged yet).  Slots combine across GPUs by an integer MAX. */
 double mgx_norm_decode(unsigned long long slot);
 

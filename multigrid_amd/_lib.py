@@ -33,7 +33,8 @@ class mgx_options(ctypes.Structure):
 class mgx_slab_op(ctypes.Structure):
     _fields_ = [
         ("struct_size", ctypes.c_int),
-        ("pro", ctypes.c_int), ("nsweeps", ctypes.c_int), ("res", ctypes.c_int), ("zero_in", ctypes.c_int),
+        ("nsweeps", ctypes.c_int), ("pro_stage", ctypes.c_int), ("norm_stage", ctypes.c_int),
+        ("restrict_out", ctypes.c_int), ("zero_in", ctypes.c_int), ("store", ctypes.c_int),
         ("v_in", ctypes.c_void_p), ("v_out", ctypes.c_void_p), ("f", ctypes.c_void_p),
         ("coarse_v", ctypes.c_void_p), ("coarse_f", ctypes.c_void_p), ("norm_slot", ctypes.c_void_p),
         ("m", ctypes.c_int), ("ld", ctypes.c_int), ("ncols", ctypes.c_int),

@@ -818,19 +818,25 @@ int mgx_slab_launch(const mgx_slab_op *op, void *stream)
     if (!op) return fail(MGX_ERR_ARG, "mgx_slab_launch: null op");
     if (op->struct_size != (int)sizeof(mgx_slab_op))
         return fail(MGX_ERR_ARG, "mgx_slab_launch: struct_size %d != %d", op->struct_size, (int)sizeof(mgx_slab_op));
-    const int ns = op->nsweeps, res = op->res, pro = op->pro ? 1 : 0, zi = op->zero_in ? 1 : 0;
+    StreamOp so;
+    so.ns = op->nsweeps;
+    so.pa = op->pro_stage;
+    so.nm = op->norm_stage;
+    so.res = op->restrict_out ? 1 : 0;
+    so.zero_in = op->zero_in ? 1 : 0;
+    so.store = op->store ? 1 : 0;
+    const int ns = so.ns;
     if (ns < 0 || ns > MGX_SLAB_MAX_SWEEPS) return fail(MGX_ERR_ARG, "mgx_slab_launch: nsweeps %d outside 0..%d", ns, MGX_SLAB_MAX_SWEEPS);
-    if (res < 0 || res > 2) return fail(MGX_ERR_ARG, "mgx_slab_launch: res %d", res);
-    if (pro && res == 1) return fail(MGX_ERR_ARG, "mgx_slab_launch: pro with res == 1 is not a leg of the V-cycle");
-    if (zi && (pro || ns < 1 || res == 2)) return fail(MGX_ERR_ARG, "mgx_slab_launch: zero_in needs pro == 0, nsweeps >= 1, res != 2");
+    if (so.pa < -1 || so.pa > ns || so.nm < -1 || so.nm > ns)
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: pro_stage %d / norm_stage %d outside -1..%d", so.pa, so.nm, ns);
+    if (so.store && ns == 0 && so.pa < 0) return fail(MGX_ERR_ARG, "mgx_slab_launch: store with nothing computed");
     if (op->m < 3) return fail(MGX_ERR_ARG, "mgx_slab_launch: m %d < 3", op->m);
     if (op->ld < op->m || op->ncols < 1) return fail(MGX_ERR_ARG, "mgx_slab_launch: bad pitch/ncols");
-    if (!op->f || (!zi && !op->v_in)) return fail(MGX_ERR_ARG, "mgx_slab_launch: null input");
-    const bool writes_v = pro || ns >= 1;
-    if (writes_v && !op->v_out) return fail(MGX_ERR_ARG, "mgx_slab_launch: null v_out");
-    if (writes_v && op->v_out == op->v_in) return fail(MGX_ERR_ARG, "mgx_slab_launch: v_out must not alias v_in");
-    if (!writes_v && res == 0) return MGX_OK;
-    if ((pro && !op->coarse_v) || (res == 1 && !op->coarse_f) || (res == 2 && !op->norm_slot))
+    if (!op->f || (!so.zero_in && !op->v_in)) return fail(MGX_ERR_ARG, "mgx_slab_launch: null input");
+    if (so.store && !op->v_out) return fail(MGX_ERR_ARG, "mgx_slab_launch: null v_out");
+    if (so.store && !so.zero_in && op->v_out == op->v_in) return fail(MGX_ERR_ARG, "mgx_slab_launch: v_out must not alias v_in");
+    if (!so.store && !so.res && so.nm < 0) return MGX_OK;
+    if ((so.pa >= 0 && !op->coarse_v) || (so.res && !op->coarse_f) || (so.nm >= 0 && !op->norm_slot))
         return fail(MGX_ERR_ARG, "mgx_slab_launch: null coarse array or norm slot");
     if (op->jlo < 0 || op->jhi > op->ncols || op->jlo > op->jhi)
         return fail(MGX_ERR_ARG, "mgx_slab_launch: produced range [%d,%d) outside 0..%d", op->jlo, op->jhi, op->ncols);
@@ -841,24 +847,25 @@ int mgx_slab_launch(const mgx_slab_op *op, void *stream)
     if ((flo == 0 && op->jlo < 1) || (fhi >= 0 && op->jhi > fhi))
         return fail(MGX_ERR_ARG, "mgx_slab_launch: a Dirichlet column cannot be produced");
     // halo the pipeline consumes around the produced columns
-    const int need_lo = ns + (res == 1 ? 2 : res == 2 ? 1 : 0);
-    const int need_hi = ns + (res == 1 ? 2 : res == 2 ? 1 : 0);
-    if (flo < 0 && op->jlo - need_lo < 0)
-        return fail(MGX_ERR_ARG, "mgx_slab_launch: %d halo columns needed left of column %d", need_lo, op->jlo);
-    if (fhi < 0 && op->jhi - 1 + need_hi > op->ncols - 1)
-        return fail(MGX_ERR_ARG, "mgx_slab_launch: %d halo columns needed right of column %d", need_hi, op->jhi - 1);
-    if (pro || res == 1) {
+    const int need = stream_halo(so);
+    if (flo < 0 && op->jlo - need < 0)
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: %d halo columns needed left of column %d", need, op->jlo);
+    if (fhi < 0 && op->jhi - 1 + need > op->ncols - 1)
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: %d halo columns needed right of column %d", need, op->jhi - 1);
+    if (so.pa >= 0 || so.res) {
         if (op->mc != (op->m - 1) / 2 + 1 || op->ldc < op->mc || op->nccols < 1)
             return fail(MGX_ERR_ARG, "mgx_slab_launch: coarse slab %d rows does not pair with %d fine rows", op->mc, op->m);
-        // coarse columns touched: interpolation reads J and J+1 of every input
-        // column, restriction writes J of the produced even columns
+        // coarse columns touched: interpolation reads J and J+1 of every column
+        // of stage pro_stage that the produced range depends on; restriction
+        // writes J of the produced even columns
         int jf_lo = op->jlo, jf_hi = op->jhi - 1;
-        if (pro) {
-            jf_lo = op->jlo - need_lo < 0 ? 0 : op->jlo - need_lo;
-            jf_hi = op->jhi - 1 + need_hi > op->ncols - 1 ? op->ncols - 1 : op->jhi - 1 + need_hi;
+        if (so.pa >= 0) {
+            const int reach = need - so.pa;
+            jf_lo = op->jlo - reach < 0 ? 0 : op->jlo - reach;
+            jf_hi = op->jhi - 1 + reach > op->ncols - 1 ? op->ncols - 1 : op->jhi - 1 + reach;
         }
         const int Jlo = ((jf_lo + op->gf0) >> 1) - op->gc0;
-        const int Jhi = ((jf_hi + op->gf0 + (pro ? 1 : 0)) >> 1) - op->gc0;
+        const int Jhi = ((jf_hi + op->gf0 + (so.pa >= 0 ? 1 : 0)) >> 1) - op->gc0;
         if (Jlo < 0 || Jhi > op->nccols - 1)
             return fail(MGX_ERR_ARG, "mgx_slab_launch: coarse columns %d..%d outside the coarse slab 0..%d", Jlo, Jhi,
                         op->nccols - 1);
@@ -884,7 +891,11 @@ int mgx_slab_launch(const mgx_slab_op *op, void *stream)
     A.gf0 = op->gf0;
     A.gc0 = op->gc0;
     A.c = make_coef(op->dx, op->omega);
-    HIP_TRY(launch_stream(pro, ns, res, zi, A, (hipStream_t)stream));
+    const hipError_t e = launch_stream(so, A, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue)
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: no kernel for nsweeps=%d pro_stage=%d norm_stage=%d restrict=%d zero_in=%d "
+                                 "store=%d (see the leg list in include/mgx.h)", so.ns, so.pa, so.nm, so.res, so.zero_in, so.store);
+    HIP_TRY(e);
     return MGX_OK;
 }
 

@@ -35,8 +35,9 @@ from .solver import MGOutputs
 
 class SlabOp:
     """Arguments of one fused slab launch (mirrors mgx_slab_op in include/mgx.h)."""
-    __slots__ = ("pro", "nsweeps", "res", "zero_in", "v_in", "v_out", "f", "coarse_v", "coarse_f", "norm_slot",
-                 "m", "ncols", "mc", "nccols", "jlo", "jhi", "jfix_lo", "jfix_hi", "gf0", "gc0", "dx", "omega")
+    __slots__ = ("nsweeps", "pro_stage", "norm_stage", "restrict_out", "zero_in", "store", "v_in", "v_out", "f",
+                 "coarse_v", "coarse_f", "norm_slot", "m", "ncols", "mc", "nccols", "jlo", "jhi", "jfix_lo", "jfix_hi",
+                 "gf0", "gc0", "dx", "omega")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -73,7 +74,8 @@ class HipBackend:
     def launch(self, op):
         o = _lib.mgx_slab_op()
         o.struct_size = ctypes.sizeof(_lib.mgx_slab_op)
-        o.pro, o.nsweeps, o.res, o.zero_in = int(op.pro), int(op.nsweeps), int(op.res), int(op.zero_in)
+        o.nsweeps, o.pro_stage, o.norm_stage = int(op.nsweeps), int(op.pro_stage), int(op.norm_stage)
+        o.restrict_out, o.zero_in, o.store = int(op.restrict_out), int(op.zero_in), int(op.store)
         o.v_in = op.v_in.data_ptr() if op.v_in is not None else None
         o.v_out = op.v_out.data_ptr() if op.v_out is not None else None
         o.f = op.f.data_ptr()
@@ -335,8 +337,20 @@ class SlabSolver:
             self.be.launch(op)
 
     # ---- the cycle -------------------------------------------------------------------
-    def _chain(self, level, name, Lv, pro, ns, res, zero_in, **kw):
-        """[pro] -> ns sweeps -> [res] as launches of at most SLAB_MAX_SWEEPS sweeps."""
+    def _op(self, Lv, nsweeps, pro_stage=-1, norm_stage=-1, restrict_out=0, zero_in=0, store=1, omega=0.0, v_in=None,
+            v_out=None, coarse=None, coarse_v=None, coarse_f=None, norm_slot=None):
+        mc, nccols, gc0 = coarse if coarse is not None else (0, 0, 0)
+        return SlabOp(nsweeps=nsweeps, pro_stage=pro_stage, norm_stage=norm_stage, restrict_out=restrict_out,
+                      zero_in=zero_in, store=store, v_in=v_in, v_out=v_out, f=Lv.f, coarse_v=coarse_v,
+                      coarse_f=coarse_f, norm_slot=norm_slot, m=Lv.m, ncols=Lv.ncols, mc=mc, nccols=nccols,
+                      jlo=Lv.jlo, jhi=Lv.jhi, jfix_lo=Lv.jfix_lo, jfix_hi=Lv.jfix_hi, gf0=Lv.lo, gc0=gc0, dx=Lv.dx,
+                      omega=omega)
+
+    def _chain(self, level, name, Lv, pro, ns, res, zero_in, omega, coarse=None, coarse_v=None, coarse_f=None,
+               norm_slot=None):
+        """[pro] -> ns sweeps -> [res: 1 restrict, 2 norm] as launches of at most SLAB_MAX_SWEEPS
+        sweeps; every launch that stores the iterate flips the level's ping-pong buffers, and
+        between two launches of a chain the halo columns are exchanged."""
         remaining, first = ns, True
         while True:
             k = min(remaining, _lib.SLAB_MAX_SWEEPS)
@@ -346,18 +360,16 @@ class SlabSolver:
             rs = res if last else 0
             zi = zero_in if first else 0
             if k > 0 or pr or rs:
-                op = SlabOp(pro=pr, nsweeps=k, res=rs, zero_in=zi, v_in=Lv.v[Lv.cur], v_out=Lv.v[Lv.cur ^ 1], f=Lv.f,
-                            m=Lv.m, ncols=Lv.ncols, jlo=Lv.jlo, jhi=Lv.jhi, jfix_lo=Lv.jfix_lo, jfix_hi=Lv.jfix_hi,
-                            gf0=Lv.lo, dx=Lv.dx, omega=kw["omega"],
-                            coarse_v=kw.get("coarse_v") if pr else None,
-                            coarse_f=kw.get("coarse_f") if rs == 1 else None,
-                            norm_slot=kw.get("norm_slot") if rs == 2 else None,
-                            mc=kw.get("mc"), nccols=kw.get("nccols"), gc0=kw.get("gc0", 0))
+                store = 1 if (k > 0 or pr) else 0
+                op = self._op(Lv, k, pro_stage=0 if pr else -1, norm_stage=k if rs == 2 else -1,
+                              restrict_out=1 if rs == 1 else 0, zero_in=zi, store=store, omega=omega,
+                              v_in=Lv.v[Lv.cur], v_out=Lv.v[Lv.cur ^ 1], coarse=coarse,
+                              coarse_v=coarse_v if pr else None, coarse_f=coarse_f if rs == 1 else None,
+                              norm_slot=norm_slot if rs == 2 else None)
                 self._launch(level, name, op)
-                if k > 0 or pr:
+                if store:
                     Lv.cur ^= 1
                     if not last:
-                        # the next launch of the chain reads halo columns of what this one wrote
                         self._exchange_v(Lv)
             first = False
             if remaining <= 0:
@@ -375,29 +387,41 @@ class SlabSolver:
         self.comm.exchange([(self.be.comm_tensor(Lv.v[Lv.cur]),) + self._halo_ranges(Lv)])
 
     def _coarse_of(self, l):
-        """(coarse f array, coarse v getter, mc, nccols, gc0) of distributed level l."""
+        """(coarse level or None for the tail, (mc, nccols, gc0)) of distributed level l."""
         if l + 1 < self.ndist:
             C = self.levels[l + 1]
-            return C, C.m, C.ncols, C.lo
-        return None, self.dims[self.ndist], self.dims[self.ndist], 0
+            return C, (C.m, C.ncols, C.lo)
+        return None, (self.dims[self.ndist], self.dims[self.ndist], 0)
 
-    def _vcycle(self, Ndown, Nup, omega, norm_slot):
-        nd = self.ndist
-        for l in range(nd):  # main.cpp:317-328
-            Lv = self.levels[l]
-            C, mc, nccols, gc0 = self._coarse_of(l)
-            cf = C.f if C is not None else self.tail_f
-            zero_in = 1 if (l >= 1 and Ndown >= 1) else 0
-            self._chain(l, "k_stream:down", Lv, 0, Ndown, 1, zero_in, omega=omega, coarse_f=cf, mc=mc, nccols=nccols,
-                        gc0=gc0)
-            items = [(self.be.comm_tensor(Lv.v[Lv.cur]),) + self._halo_ranges(Lv)]
-            if C is not None:
-                items.append((self.be.comm_tensor(C.f),) + self._halo_ranges(C))
+    @staticmethod
+    def _lean(Ndown, Nup):
+        """Few enough sweeps for the byte-saving legs: on levels >= 1 the down leg stores
+        nothing and the up leg recomputes its sweeps from f; on level 0 the up leg of a cycle
+        and the down leg of the next are one launch."""
+        return 1 <= Ndown + Nup <= _lib.SLAB_MAX_SWEEPS
+
+    def _down(self, l, Ndown, Nup, omega):
+        """Down leg of distributed level l (main.cpp:321-327) and the exchanges it implies."""
+        Lv = self.levels[l]
+        C, cshape = self._coarse_of(l)
+        cf = C.f if C is not None else self.tail_f
+        items = []
+        if l >= 1 and (self._lean(Ndown, Nup) or Ndown == 0):
+            # the iterate is zero here: f -> coarse f, nothing stored
+            op = self._op(Lv, Ndown, restrict_out=1, zero_in=1, store=0, omega=omega, coarse=cshape, coarse_f=cf)
+            self._launch(l, "k_stream:down", op)
+        else:
+            self._chain(l, "k_stream:down", Lv, 0, Ndown, 1, 1 if l >= 1 else 0, omega, coarse=cshape, coarse_f=cf)
+            items.append((self.be.comm_tensor(Lv.v[Lv.cur]),) + self._halo_ranges(Lv))
+        if C is not None:
+            items.append((self.be.comm_tensor(C.f),) + self._halo_ranges(C))
+        if items:
             self.comm.exchange(items)
-        # the tail: all-gather its right-hand side, run it on every rank
+
+    def _tail(self, Ndown, Nup, omega):
+        """All-gather the tail's right-hand side and run the tail on every rank."""
         R, g = self.comm.size, self.comm.rank
         tb = self.tail_b
-        mt = self.dims[nd]
         if R > 1:
             n_own = tb[g + 1] - tb[g]
             self.tail_send[:n_own] = self.tail_f[tb[g]:tb[g + 1]]
@@ -405,18 +429,36 @@ class SlabSolver:
             for k in range(R):
                 if k != g:
                     self.tail_f[tb[k]:tb[k + 1]] = allc[k * self.tail_pad:k * self.tail_pad + (tb[k + 1] - tb[k])]
-        vt = self.tail.run(self.tail_f, Ndown, Nup, omega)
-        del mt
-        for l in range(nd - 1, -1, -1):  # main.cpp:335-346
-            Lv = self.levels[l]
-            C, mc, nccols, gc0 = self._coarse_of(l)
-            cv = C.v[C.cur] if C is not None else vt
-            res = 2 if (l == 0 and norm_slot is not None) else 0
-            self._chain(l, "k_stream:up", Lv, 1, Nup, res, 0, omega=omega, coarse_v=cv, norm_slot=norm_slot, mc=mc,
-                        nccols=nccols, gc0=gc0)
-            self._exchange_v(Lv)
-            if Ndown == 0 and C is not None:  # main.cpp:345 (otherwise the next down leg ignores the coarse iterate)
-                C.v[C.cur][:] = 0.0
+        return self.tail.run(self.tail_f, Ndown, Nup, omega)
+
+    def _up(self, l, Ndown, Nup, omega, vt, norm_slot=None, next_down=False):
+        """Up leg of distributed level l (main.cpp:337-344); on level 0 with the norm of
+        main.cpp:351 and, if next_down, the down leg of the following cycle."""
+        Lv = self.levels[l]
+        C, cshape = self._coarse_of(l)
+        cv = C.v[C.cur] if C is not None else vt
+        items = []
+        if l >= 1 and self._lean(Ndown, Nup):
+            op = self._op(Lv, Ndown + Nup, pro_stage=Ndown, zero_in=1, store=1, omega=omega, v_out=Lv.v[0],
+                          coarse=cshape, coarse_v=cv)
+            Lv.cur = 0
+            self._launch(l, "k_stream:up", op)
+        elif l >= 1 and Ndown == 0:
+            self._chain(l, "k_stream:up", Lv, 1, Nup, 0, 1, omega, coarse=cshape, coarse_v=cv)
+        elif next_down:
+            cf = C.f if C is not None else self.tail_f
+            op = self._op(Lv, Nup + Ndown, pro_stage=0, norm_stage=Nup, restrict_out=1, store=1, omega=omega,
+                          v_in=Lv.v[Lv.cur], v_out=Lv.v[Lv.cur ^ 1], coarse=cshape, coarse_v=cv, coarse_f=cf,
+                          norm_slot=norm_slot)
+            Lv.cur ^= 1
+            self._launch(l, "k_stream:updown", op)
+            if C is not None:
+                items.append((self.be.comm_tensor(C.f),) + self._halo_ranges(C))
+        else:
+            self._chain(l, "k_stream:up", Lv, 1, Nup, 2 if norm_slot is not None else 0, 0, omega, coarse=cshape,
+                        coarse_v=cv, norm_slot=norm_slot)
+        items.append((self.be.comm_tensor(Lv.v[Lv.cur]),) + self._halo_ranges(Lv))
+        self.comm.exchange(items)
 
     def cycles(self, Nv, Ndown, Nup, omega, pureJacobi=False):
         """Nv cycles (main.cpp:309-354).  Returns MGOutputs; Times is the cumulative wall
@@ -425,16 +467,26 @@ class SlabSolver:
         be = self.be
         slots = be.slots(Nv + 1)
         L0 = self.levels[0]
+        nd = self.ndist
+        lean = self._lean(Ndown, Nup)
         # main.cpp:307: the norm of the initial residual (halo columns of v must be current)
         self._exchange_v(L0)
-        self._chain(0, "k_stream:norm", L0, 0, 0, 2, 0, omega=omega, norm_slot=be.slot_ptr(slots, 0))
+        self._chain(0, "k_stream:norm", L0, 0, 0, 2, 0, omega, norm_slot=be.slot_ptr(slots, 0))
         times = np.zeros(Nv + 1)
         for it in range(Nv):
             t0 = time.perf_counter()
+            slot = be.slot_ptr(slots, it + 1)
             if not pureJacobi:
-                self._vcycle(Ndown, Nup, omega, be.slot_ptr(slots, it + 1))
+                if it == 0 or not lean:  # otherwise the previous cycle's level-0 launch did it
+                    self._down(0, Ndown, Nup, omega)
+                for l in range(1, nd):  # main.cpp:317-328
+                    self._down(l, Ndown, Nup, omega)
+                vt = self._tail(Ndown, Nup, omega)
+                for l in range(nd - 1, 0, -1):  # main.cpp:335-346
+                    self._up(l, Ndown, Nup, omega, vt)
+                self._up(0, Ndown, Nup, omega, vt, norm_slot=slot, next_down=lean and it + 1 < Nv)
             else:  # main.cpp:348 and :351 in one pass
-                self._chain(0, "k_stream:up", L0, 0, 1, 2, 0, omega=omega, norm_slot=be.slot_ptr(slots, it + 1))
+                self._chain(0, "k_stream:up", L0, 0, 1, 2, 0, omega, norm_slot=slot)
                 self._exchange_v(L0)
             times[it + 1] = times[it] + (time.perf_counter() - t0)
         self.comm.allreduce_max_(slots)

@@ -80,6 +80,30 @@ class NumpyBackend:
     def make_tail(self, m, dx, coarsest):
         return _OracleTail(self.O, m, dx, coarsest)
 
+    def _correction(self, op, ncols, m):
+        c = op.coarse_v
+        j = np.arange(ncols)
+        jg = j + op.gf0
+        J = np.clip((jg >> 1) - op.gc0, 0, op.nccols - 1)
+        J1 = np.clip(J + 1, 0, op.nccols - 1)
+        odd_j = (jg & 1) == 1
+        i = np.arange(m)
+        I = i >> 1
+        I1 = np.clip(I + 1, 0, op.mc - 1)
+        odd_i = (i & 1) == 1
+        c00 = c[J][:, I]
+        c10 = c[J][:, I1]      # row I+1, column J
+        c01 = c[J1][:, I]      # row I,   column J+1
+        c11 = c[J1][:, I1]
+        p_ee = c00                                   # main.cpp:236
+        p_eo = 0.5 * (c00 + c01)                     # i even, j odd  (:239)
+        p_oe = 0.5 * (c00 + c10)                     # i odd,  j even (:242)
+        s4 = c00 + c10
+        s4 = s4 + c01
+        s4 = s4 + c11
+        p_oo = 0.25 * s4                             # :245
+        return np.where(odd_i[None, :], np.where(odd_j[:, None], p_oo, p_oe), np.where(odd_j[:, None], p_eo, p_ee))
+
     def launch(self, op):
         m, ncols = op.m, op.ncols
         h2 = op.dx * op.dx
@@ -87,69 +111,48 @@ class NumpyBackend:
         omega, nomega = op.omega, 1 - op.omega
         fixed = [j for j in (op.jfix_lo, op.jfix_hi) if j is not None and j >= 0]
         u = np.zeros((ncols, m)) if op.zero_in else np.array(op.v_in, copy=True)
-        if op.pro:
-            c = op.coarse_v
-            j = np.arange(ncols)
-            jg = j + op.gf0
-            J = np.clip((jg >> 1) - op.gc0, 0, op.nccols - 1)
-            J1 = np.clip(J + 1, 0, op.nccols - 1)
-            odd_j = (jg & 1) == 1
-            i = np.arange(m)
-            I = i >> 1
-            I1 = np.clip(I + 1, 0, op.mc - 1)
-            odd_i = (i & 1) == 1
-            c00 = c[J][:, I]
-            c10 = c[J][:, I1]      # row I+1, column J
-            c01 = c[J1][:, I]      # row I,   column J+1
-            c11 = c[J1][:, I1]
-            p_ee = c00                                   # main.cpp:236
-            p_eo = 0.5 * (c00 + c01)                     # i even, j odd  (:239)
-            p_oe = 0.5 * (c00 + c10)                     # i odd,  j even (:242)
-            s4 = c00 + c10
-            s4 = s4 + c01
-            s4 = s4 + c11
-            p_oo = 0.25 * s4                             # :245
-            P = np.where(odd_i[None, :], np.where(odd_j[:, None], p_oo, p_oe), np.where(odd_j[:, None], p_eo, p_ee))
-            add = u + P                                  # main.cpp:341
-            mask = np.ones((ncols, m), dtype=bool)
-            mask[:, 0] = mask[:, -1] = False
-            for jf in fixed:
-                mask[jf, :] = False
-            u = np.where(mask, add, u)
-        for _ in range(op.nsweeps):
-            new = u.copy()
-            new[1:-1, 1:-1] = _jacobi(u, op.f, h2, omega, nomega)
-            for jf in fixed:
-                new[jf, :] = u[jf, :]
-            u = new
-        if op.pro or op.nsweeps >= 1:
-            op.v_out[op.jlo:op.jhi, 1:m - 1] = u[op.jlo:op.jhi, 1:m - 1]
-        if op.res:
-            r = np.zeros((ncols, m))
-            r[1:-1, 1:-1] = _residual(u, op.f, invh2)
-            if op.res == 2:
+        for s in range(op.nsweeps + 1):
+            if s > 0:
+                new = u.copy()
+                new[1:-1, 1:-1] = _jacobi(u, op.f, h2, omega, nomega)
+                for jf in fixed:
+                    new[jf, :] = u[jf, :]
+                u = new
+            if op.pro_stage == s:
+                add = u + self._correction(op, ncols, m)     # main.cpp:341
+                mask = np.ones((ncols, m), dtype=bool)
+                mask[:, 0] = mask[:, -1] = False
+                for jf in fixed:
+                    mask[jf, :] = False
+                u = np.where(mask, add, u)
+            if op.norm_stage == s:
+                r = np.zeros((ncols, m))
+                r[1:-1, 1:-1] = _residual(u, op.f, invh2)
                 slots, k = op.norm_slot
                 val = float(np.max(np.abs(r[op.jlo:op.jhi, 1:m - 1]))) if op.jhi > op.jlo else 0.0
-                val = max(val, 0.0)
-                slots[k] = max(int(slots[k]), _encode(val))
-            else:
-                cf = op.coarse_f
-                for j in range(op.jlo, op.jhi):
-                    jg = j + op.gf0
-                    if jg & 1:
-                        continue
-                    Jc = (jg >> 1) - op.gc0
-                    I = np.arange(1, op.mc - 1)
-                    a = r[j, 2 * I] * 0.25                                  # main.cpp:216-218
-                    nb = r[j, 2 * I - 1] + r[j, 2 * I + 1]
-                    nb = nb + r[j - 1, 2 * I]
-                    nb = nb + r[j + 1, 2 * I]
-                    nb = nb * 0.125
-                    cn = r[j - 1, 2 * I - 1] + r[j - 1, 2 * I + 1]
-                    cn = cn + r[j - 1, 2 * I + 1]
-                    cn = cn + r[j + 1, 2 * I + 1]
-                    cn = cn * 0.0625
-                    cf[Jc, 1:op.mc - 1] = (a + nb) + cn
+                slots[k] = max(int(slots[k]), _encode(max(val, 0.0)))
+        if op.store:
+            op.v_out[op.jlo:op.jhi, 1:m - 1] = u[op.jlo:op.jhi, 1:m - 1]
+        if op.restrict_out:
+            r = np.zeros((ncols, m))
+            r[1:-1, 1:-1] = _residual(u, op.f, invh2)
+            cf = op.coarse_f
+            for j in range(op.jlo, op.jhi):
+                jg = j + op.gf0
+                if jg & 1:
+                    continue
+                Jc = (jg >> 1) - op.gc0
+                I = np.arange(1, op.mc - 1)
+                a = r[j, 2 * I] * 0.25                                  # main.cpp:216-218
+                nb = r[j, 2 * I - 1] + r[j, 2 * I + 1]
+                nb = nb + r[j - 1, 2 * I]
+                nb = nb + r[j + 1, 2 * I]
+                nb = nb * 0.125
+                cn = r[j - 1, 2 * I - 1] + r[j - 1, 2 * I + 1]
+                cn = cn + r[j - 1, 2 * I + 1]
+                cn = cn + r[j + 1, 2 * I + 1]
+                cn = cn * 0.0625
+                cf[Jc, 1:op.mc - 1] = (a + nb) + cn
 
 
 class _OracleTail:

@@ -53,7 +53,7 @@ def test_slab_launch_rejects_missing_halo(mg):
     t = mg.colmajor(65, 20)
     o = _lib.mgx_slab_op()
     o.struct_size = ctypes.sizeof(_lib.mgx_slab_op)
-    o.pro, o.nsweeps, o.res, o.zero_in = 0, 2, 0, 0
+    o.nsweeps, o.pro_stage, o.norm_stage, o.restrict_out, o.zero_in, o.store = 2, -1, -1, 0, 0, 1
     o.v_in, o.v_out, o.f = t.data_ptr(), mg.colmajor(65, 20).data_ptr(), t.data_ptr()
     o.m, o.ld, o.ncols = 65, 65, 20
     o.jlo, o.jhi, o.jfix_lo, o.jfix_hi = 1, 19, -1, -1   # needs 2 halo columns on each side, has 1
