@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgx.so")
+# MGX_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("MGX_LIB") or os.path.join(_HERE, "libmgx.so")
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _vp = ctypes.c_void_p

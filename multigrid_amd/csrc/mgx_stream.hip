@@ -49,6 +49,7 @@
 // (mgx_kernels.hip), so both schedules produce identical bits.
 #include "mgx_internal.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace mgx {
@@ -107,7 +108,10 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
     using G = Geo<NS, PA, NM, RES>;
     constexpr bool PRO = PA >= 0;
     constexpr bool NORM = NM >= 0;
-    constexpr int PF = 2;  // columns of load-ahead
+#ifndef MGX_PF
+#define MGX_PF 2
+#endif
+    constexpr int PF = MGX_PF;  // columns of load-ahead
     const int lane = threadIdx.x & 63;
     const int m = A.m;
     const size_t ld = (size_t)A.ld;
@@ -384,9 +388,12 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
     if (ncolsout <= 0 || m < 3) return hipSuccess;
     // chunk length: long enough to amortise the pipeline warm-up, short enough
     // that a small level still spreads over the chip
-    int CJ = 128;
+    static const int cj_max = [] { const char *e = getenv("MGX_CJ"); return e ? atoi(e) : 256; }();
+    static const int cj_min = [] { const char *e = getenv("MGX_CJ_MIN"); return e ? atoi(e) : 16; }();
+    static const int min_blocks = [] { const char *e = getenv("MGX_MIN_BLOCKS"); return e ? atoi(e) : 2048; }();
+    int CJ = cj_max;
     const int nsg = (A.nstrips + 3) / 4;
-    while (CJ > 16 && (long)nsg * ((ncolsout + CJ - 1) / CJ) < 2048) CJ >>= 1;
+    while (CJ > cj_min && (long)nsg * ((ncolsout + CJ - 1) / CJ) < min_blocks) CJ >>= 1;
     A.CJ = CJ;
     A.nchunks = (ncolsout + CJ - 1) / CJ;
     hipLaunchKernelGGL((k_stream<NS, PA, NM, RES, ZERO_IN, STORE>), dim3((unsigned)nsg, (unsigned)A.nchunks),
