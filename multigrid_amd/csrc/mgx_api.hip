@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -70,6 +71,7 @@ struct mgx_plan {
     int verbose = 0;
     int coarsest = 2;
     int depth = 0;
+    int use_tail = 1;  // levels <= 65x65 of a cycle in one LDS-resident launch (MGX_NO_TAIL=1 disables)
     std::vector<Level> lv;
     double *r = nullptr;                 // residual scratch of the stepwise schedule (fine size)
     unsigned long long *slots = nullptr; // encoded norms, one per cycle (+1)
@@ -347,21 +349,70 @@ int fused_up(mgx_plan *p, int d, const FusedCtx &cx, unsigned long long *slot, b
     return stream_chain(p, d, MGX_KERNEL_FUSED_UP, p->stream, 1, cx.Nup, slot ? 2 : 0, 0, A, L.v, L.cur);
 }
 
+// First level of the LDS-resident tail: the first zero-start level of at most
+// TAIL_MAX_M points per side (level 0 only when it starts from zero), or -1.
+int tail_first_level(const mgx_plan *p, const FusedCtx &cx)
+{
+    if (!p->use_tail) return -1;
+    for (int d = cx.zero0 ? 0 : 1; d <= p->depth; d++) {
+        if (p->lv[d].m > TAIL_MAX_M) continue;
+        if (p->depth - d + 1 > TAIL_MAX_LEVELS) return -1;
+        size_t n = 0;
+        for (int k = d; k <= p->depth; k++) n += 3 * p->lv[k].n() * sizeof(double);
+        return n <= TAIL_MAX_LDS_BYTES ? d : -1;
+    }
+    return -1;
+}
+
+// Levels T..depth of one cycle in a single launch; the result is lv[T].v[0].
+int fused_tail(mgx_plan *p, int T, const FusedCtx &cx)
+{
+    TailArgs A;
+    Level &L = p->lv[T];
+    A.f = L.f;
+    A.v = L.v[0];
+    A.ld = L.m;
+    A.nlev = p->depth - T + 1;
+    for (int k = 0; k < A.nlev; k++) {
+        const Level &K = p->lv[T + k];
+        const SweepCoef c = make_coef(K.dx, cx.omega);
+        A.m[k] = K.m;
+        A.h2[k] = c.h2;
+        A.invh2[k] = c.invh2;
+    }
+    A.Ndown = cx.Ndown;
+    A.Nup = cx.Nup;
+    A.omega = cx.omega;
+    A.nomega = 1 - cx.omega;
+    L.cur = 0;
+    HIP_TRY(launch_tail(A, p->stream));
+    if (p->verbose && p->lv[p->depth].m != 3)
+        printf("Error: Direct solver not defined for %dx%d matrices!\n", p->lv[p->depth].m, p->lv[p->depth].m);
+    return MGX_OK;
+}
+
 // levels 1..depth-1 down, the coarsest solve, levels depth-1..1 up
 int fused_coarse_legs(mgx_plan *p, const FusedCtx &cx)
 {
     const int depth = p->depth;
-    for (int d = 1; d < depth; d++) {
+    const int T = tail_first_level(p, cx);
+    const int last = (T >= 1) ? T - 1 : depth - 1;  // last level that runs its own legs
+    for (int d = 1; d <= last; d++) {
         int rc = fused_down(p, d, cx);
         if (rc) return rc;
     }
-    Level &B = p->lv[depth];
-    if (B.m == 3) {  // main.cpp:331
-        HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, p->stream));
-    } else if (p->verbose) {
-        printf("Error: Direct solver not defined for %dx%d matrices!\n", B.m, B.m);
+    if (T >= 1) {
+        int rc = fused_tail(p, T, cx);
+        if (rc) return rc;
+    } else {
+        Level &B = p->lv[depth];
+        if (B.m == 3) {  // main.cpp:331
+            HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, p->stream));
+        } else if (p->verbose) {
+            printf("Error: Direct solver not defined for %dx%d matrices!\n", B.m, B.m);
+        }
     }
-    for (int d = depth - 1; d >= 1; d--) {
+    for (int d = last; d >= 1; d--) {
         int rc = fused_up(p, d, cx, nullptr, false);
         if (rc) return rc;
     }
@@ -372,6 +423,7 @@ int fused_coarse_legs(mgx_plan *p, const FusedCtx &cx)
 int vcycle_fused(mgx_plan *p, int Ndown, int Nup, double omega, unsigned long long *norm_slot, bool zero0 = false)
 {
     FusedCtx cx{Ndown, Nup, omega, zero0};
+    if (zero0 && tail_first_level(p, cx) == 0) return fused_tail(p, 0, cx);  // the whole plan fits the tail
     if (p->depth == 0) {
         Level &B = p->lv[0];
         if (B.m == 3) HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, p->stream));
@@ -450,6 +502,7 @@ int mgx_plan_create(mgx_plan **out, int m, double dx, int coarsest, const mgx_op
     }
     p->coarsest = coarsest;
     p->depth = depth;
+    p->use_tail = getenv("MGX_NO_TAIL") ? 0 : 1;
     p->lv.resize(depth + 1);
     double h = dx;
     for (int d = 0; d <= depth; d++) {

@@ -56,6 +56,24 @@ hipError_t launch_norminf(const double *a, size_t len, unsigned long long *slot,
 hipError_t launch_residual_norm(const double *u, const double *f, int m, int jlo, int jhi, const SweepCoef &c,
                                 unsigned long long *slot, hipStream_t s);
 
+// ---- the LDS-resident bottom of the cycle (mgx_tail.hip) -----------------------
+static constexpr int TAIL_MAX_M = 65;
+static constexpr int TAIL_MAX_LEVELS = 8;
+static constexpr size_t TAIL_MAX_LDS_BYTES = 160 * 1024;
+struct TailArgs {
+    const double *f = nullptr;  // right-hand side of the tail's top level (m[0] x m[0], pitch ld)
+    double *v = nullptr;        // receives the interior of the top level's iterate after the cycle
+    int ld = 0;
+    int nlev = 0;               // levels in the tail, top first
+    int m[TAIL_MAX_LEVELS] = {0};
+    double h2[TAIL_MAX_LEVELS] = {0}, invh2[TAIL_MAX_LEVELS] = {0};
+    int Ndown = 0, Nup = 0;
+    double omega = 0, nomega = 0;
+};
+size_t tail_lds_bytes(const TailArgs &A);
+// One V(Ndown,Nup) cycle over the tail's levels from a zero iterate on its top level.
+hipError_t launch_tail(const TailArgs &A, hipStream_t s);
+
 // ---- fused streaming kernels (mgx_stream.hip) --------------------------------
 // One launch = [prolong + correct] -> ns Jacobi sweeps -> [residual -> restrict | norm].
 struct StreamArgs {
