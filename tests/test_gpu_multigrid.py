@@ -72,7 +72,8 @@ def test_solver_matches_oracle_random_rhs(mg, O, m, Nv, nd, nu, omega, sched):
 
 
 @pytest.mark.parametrize("sched", SCHEDS)
-@pytest.mark.parametrize("m,coarsest", [(257, 4), (129, 8), (65, 1), (33, 3), (5, 4)])
+@pytest.mark.parametrize("m,coarsest", [(257, 4), (129, 8), (65, 1), (33, 3), (5, 4), (97, 6), (385, 6), (1537, 6),
+                                        (193, 3), (257, 128), (513, 64)])
 def test_other_coarsest_values(mg, O, m, coarsest, sched):
     # coarsest != 2 either ends on a grid larger than 3x3, where the reference's
     # direct solver does nothing (main.cpp:167), or changes the depth (main.cpp:286).
@@ -90,6 +91,19 @@ def test_other_coarsest_values(mg, O, m, coarsest, sched):
     out = mg.solve_host(f, v, dx, 4, 2, 2, 0.6, coarsest, schedule=sched)
     assert_bits(out.ResidualNorms, rn, "ResNorms")
     assert_bits(v, sol, "Sol")
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+def test_zero_cycles_returns_the_initial_norm_only(mg, O, sched):
+    from multigrid_amd import rhs
+    m = 33
+    f = rhs.random_np(m)
+    v0 = np.asfortranarray(np.random.default_rng(1).standard_normal((m, m)))
+    v = v0.copy(order="F")
+    out = mg.solve_host(f, v, 1.0 / 32, 0, 2, 2, 0.6, 2, schedule=sched)
+    assert out.ResidualNorms.shape == (1,) and out.Times.tolist() == [0.0]
+    assert out.ResidualNorms[0] == O.calc_norm(O.residual(v0, f, 1.0 / 32))
+    assert_bits(v, v0, "v untouched")
 
 
 @pytest.mark.parametrize("sched", SCHEDS)
