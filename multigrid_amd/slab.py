@@ -6,17 +6,23 @@ driver of the same V-cycle (main.cpp:283-357) and produces the same bits.
 Decomposition.  Every level is column-major, so a contiguous range of columns j
 is one contiguous block of memory.  The finest `ndist` levels are DISTRIBUTED:
 rank g owns the columns [b_g, b_{g+1}) of a level and stores them together with
-W halo columns copied from each neighbour.  Ownership is nested,
-b_g(fine) = 2*b_g(coarse) - 1, so the rank that owns fine column 2J owns coarse
-column J and both level transfers are local apart from the halo.  Levels from
-the first one with at most `tail_m` points per side downwards form the TAIL: its
-right-hand side is all-gathered and every rank runs the tail redundantly on its
-own GPU (identical bits everywhere), which removes the scatter on the way up.
+halo columns copied from (or recomputed for) each neighbour.  Ownership is
+nested, b_g(fine) = 2*b_g(coarse) - 1, so the rank that owns fine column 2J
+owns coarse column J and both level transfers are local apart from the halo.
+Levels from the first one with at most `tail_m` points per side downwards form
+the TAIL: its right-hand side is all-gathered and every rank runs the tail
+redundantly on its own GPU (identical bits everywhere), which removes the
+scatter on the way up.
 
-Per cycle and distributed level there are two neighbour exchanges (after the
-down leg: the smoothed iterate and the next coarser right-hand side in one
-batch; after the up leg: the corrected iterate) and one all-gather at the tail.
-Exchanges are plain point-to-point send/recv of whole columns through
+Communication per cycle with the usual few sweeps (Ndown + Nup <= 4, "lean"):
+ONE neighbour exchange -- the level-0 iterate (8 columns per side) and the
+level-1 right-hand side (a wider halo) in one batch -- and ONE all-gather at
+the tail.  The coarser distributed levels need no exchange at all: a coarse
+level's data is a deterministic function of the level-1 right-hand side, so
+each rank recomputes the few halo columns it needs (the halo widths below);
+Jacobi makes the recomputed values bit-identical to the neighbour's.  With
+more sweeps every leg is a chain of launches with an exchange after each.
+Exchanges are point-to-point send/recv of whole columns through
 torch.distributed: RCCL over xGMI with backend "nccl", or gloo for tests.
 
 The arithmetic runs through a backend object.  The product backend is
@@ -24,6 +30,7 @@ HipBackend (libmgx's mgx_slab_launch / mgx_plan_vcycle_async); tests inject a
 CPU backend to exercise this driver under gloo without a GPU.
 """
 import ctypes
+import time
 
 import numpy as np
 import torch
@@ -139,7 +146,8 @@ class _Comm:
         self.rank = dist.get_rank(group) if self.on else 0
         self.size = dist.get_world_size(group) if self.on else 1
         self.backend = dist.get_backend(group) if self.on else "none"
-        self._tag = 0
+        self.nexchanges = 0
+        self.ngathers = 0
 
     def _global(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
@@ -151,6 +159,7 @@ class _Comm:
     def exchange(self, items):
         """items: list of (tensor, send_lo, recv_lo, send_hi, recv_hi) where each entry but
         the tensor is a (start, stop) row range or None.  *_lo talk to rank-1, *_hi to rank+1."""
+        self.nexchanges += 1
         if self.size == 1:
             return
         ops, copies = [], []
@@ -183,6 +192,7 @@ class _Comm:
 
     def allgather(self, t):
         """Concatenation over ranks of equally shaped tensors along dim 0."""
+        self.ngathers += 1
         if self.size == 1:
             return t
         src = self._stage(t).contiguous()
@@ -204,11 +214,52 @@ class _Level:
     pass
 
 
+MAX_LEAN = _lib.SLAB_MAX_SWEEPS  # Ndown + Nup up to this run the lean legs
+
+
+def halo_plan(nd, Ndown, Nup):
+    """Halo widths of the lean schedule for `nd` distributed levels.
+
+    Returns (Ev, Ef): Ev[l] = columns beyond its own that a rank produces of the level-l
+    iterate on the way up (l >= 1), Ef[l] = columns beyond its own of the level-l right-hand
+    side a rank holds (received for l = 1, recomputed for l >= 2).  Derivation, with
+    NS = Ndown + Nup: the level-0 launch reads the level-1 iterate within (NS+2)/2+1 coarse
+    columns of its own; an up leg that produces e extra columns needs f within e + NS and
+    the coarser iterate within (e + Nup)/2 + 1; a down leg that produces the coarser f on e
+    extra columns needs f within 2e + Ndown + 2."""
+    NS = Ndown + Nup
+    Ev = [0] * (nd + 1)
+    Ef = [0] * (nd + 1)
+    if nd >= 2:
+        Ev[1] = (NS + 2) // 2 + 1
+        for l in range(2, nd):
+            Ev[l] = (Ev[l - 1] + Nup) // 2 + 1
+        for l in range(nd - 1, 0, -1):
+            Ef[l] = max(Ev[l] + NS, 2 * Ef[l + 1] + Ndown + 2 if l + 1 < nd else 0)
+    return Ev, Ef
+
+
+def halo_capacity(nd):
+    """Elementwise maximum of halo_plan over every lean (Ndown, Nup): what the arrays must hold."""
+    Ev = [0] * (nd + 1)
+    Ef = [0] * (nd + 1)
+    for a in range(MAX_LEAN + 1):
+        for b in range(MAX_LEAN + 1 - a):
+            if a + b == 0:
+                continue
+            ev, ef = halo_plan(nd, a, b)
+            Ev = [max(x, y) for x, y in zip(Ev, ev)]
+            Ef = [max(x, y) for x, y in zip(Ef, ef)]
+    return Ev, Ef
+
+
 class SlabSolver:
     """Nv V(Ndown,Nup) cycles of the reference's MultiGrid() on an M x M grid split into j-slabs.
 
     Call from every rank of the process group with identical arguments.  With a
     single rank (no process group) it degenerates to one slab plus the tail."""
+
+    W0 = 8  # halo columns of the level-0 arrays (the level-0 launch reads Ndown+Nup+2 <= 6)
 
     def __init__(self, M, dx, coarsest=2, schedule=_lib.SCHEDULE_DEFAULT, backend=None, group=None, tail_m=2049,
                  halo=8):
@@ -229,47 +280,59 @@ class SlabSolver:
             if dims[-1] < 3 or dims[-1] % 2 == 0:
                 raise ValueError("level of size %d: the reference indexes out of range there" % dims[-1])
         self.dims, self.hs = dims, hs
-        R, W = self.comm.size, halo
-        self.W = W
-        # first level of the tail: small enough, and every rank must own >= W columns above it
+        R = self.comm.size
+        self.W0 = max(halo, SlabSolver.W0)
+        # levels 0..nd-1 are distributed, level nd is the top of the tail
         nd = 0
-        while nd < self.depth and dims[nd] > tail_m and (dims[nd + 1] - 2) // R >= max(W, 1):
+        while nd < self.depth and dims[nd] > tail_m:
+            # would every rank still own at least a halo's worth of columns of every
+            # level if one more level were distributed?
+            Ev, Ef = halo_capacity(nd + 1)
+            base = (dims[nd + 1] - 2) // R  # least number of columns a rank owns of the would-be tail top
+            fits = base >= 1
+            for l in range(nd + 1):
+                own = base * (1 << (nd + 1 - l)) - 1
+                need = self.W0 if l == 0 else max(self.W0, Ef[l], Ev[l])
+                fits = fits and own >= need
+            if R > 1 and not fits:
+                break
             nd += 1
         if nd == 0:
             raise ValueError("grid %d is not split over %d rank(s) with tail_m=%d: solve it with "
                              "multigrid_amd.MultiGrid on one GPU" % (M, R, tail_m))
         self.ndist = nd
+        Ev_max, Ef_max = halo_capacity(nd)
+        mt = dims[nd]
+        b = [0] + [1 + (g * (mt - 2)) // R for g in range(1, R)] + [mt]  # ownership on the tail's top level
+        bounds = {nd: b}
+        for l in range(nd - 1, -1, -1):
+            bc = bounds[l + 1]
+            bounds[l] = [0] + [2 * bc[g] - 1 for g in range(1, R)] + [dims[l]]
+        self.bounds = bounds
+        g = self.comm.rank
         self.levels = []
-        if nd > 0:
-            mt = dims[nd]
-            b = [0] + [1 + (g * (mt - 2)) // R for g in range(1, R)] + [mt]  # ownership on the tail's finest level
-            bounds = {nd: b}
-            for l in range(nd - 1, -1, -1):
-                bc = bounds[l + 1]
-                bounds[l] = [0] + [2 * bc[g] - 1 for g in range(1, R)] + [dims[l]]
-            self.bounds = bounds
-            g = self.comm.rank
-            for l in range(nd):
-                Lv = _Level()
-                Lv.m, Lv.dx = dims[l], hs[l]
-                Lv.b0, Lv.b1 = bounds[l][g], bounds[l][g + 1]
-                Lv.lo, Lv.hi = max(0, Lv.b0 - W), min(dims[l], Lv.b1 + W)
-                Lv.ncols = Lv.hi - Lv.lo
-                Lv.o0, Lv.o1 = Lv.b0 - Lv.lo, Lv.b1 - Lv.lo              # owned, local
-                Lv.jlo, Lv.jhi = max(Lv.b0, 1) - Lv.lo, min(Lv.b1, dims[l] - 1) - Lv.lo  # produced, local
-                Lv.jfix_lo = 0 if Lv.lo == 0 else -1
-                Lv.jfix_hi = Lv.ncols - 1 if Lv.hi == dims[l] else -1
-                if Lv.b1 - Lv.b0 < W and R > 1:
-                    raise ValueError("rank %d owns %d < %d columns of level %d" % (g, Lv.b1 - Lv.b0, W, l))
-                Lv.f = self.be.zeros(Lv.ncols, Lv.m)
-                Lv.v = [self.be.zeros(Lv.ncols, Lv.m), self.be.zeros(Lv.ncols, Lv.m)]
-                Lv.cur = 0
-                self.levels.append(Lv)
-            # the tail's finest level: produced coarse columns of this rank, padded to a common count
-            self.tail_b = bounds[nd]
-            self.tail_pad = max(bounds[nd][k + 1] - bounds[nd][k] for k in range(R))
-            self.tail_send = self.be.zeros(self.tail_pad, dims[nd])
-            self.tail_f = self.be.zeros(dims[nd], dims[nd])
+        for l in range(nd):
+            Lv = _Level()
+            Lv.index = l
+            Lv.m, Lv.dx = dims[l], hs[l]
+            Lv.W = self.W0 if l == 0 else max(self.W0, Ef_max[l], Ev_max[l])  # halo columns the arrays hold
+            Lv.b0, Lv.b1 = bounds[l][g], bounds[l][g + 1]
+            Lv.lo, Lv.hi = max(0, Lv.b0 - Lv.W), min(dims[l], Lv.b1 + Lv.W)
+            Lv.ncols = Lv.hi - Lv.lo
+            Lv.o0, Lv.o1 = Lv.b0 - Lv.lo, Lv.b1 - Lv.lo                # owned, local
+            Lv.jfix_lo = 0 if Lv.lo == 0 else -1
+            Lv.jfix_hi = Lv.ncols - 1 if Lv.hi == dims[l] else -1
+            if Lv.b1 - Lv.b0 < Lv.W and R > 1:
+                raise ValueError("rank %d owns %d < %d columns of level %d" % (g, Lv.b1 - Lv.b0, Lv.W, l))
+            Lv.f = self.be.zeros(Lv.ncols, Lv.m)
+            Lv.v = [self.be.zeros(Lv.ncols, Lv.m), self.be.zeros(Lv.ncols, Lv.m)]
+            Lv.cur = 0
+            self.levels.append(Lv)
+        # the tail's top level: the coarse columns this rank produces, padded to a common count
+        self.tail_b = bounds[nd]
+        self.tail_pad = max(bounds[nd][k + 1] - bounds[nd][k] for k in range(R))
+        self.tail_send = self.be.zeros(self.tail_pad, dims[nd])
+        self.tail_f = self.be.zeros(dims[nd], dims[nd])
         self.tail = self.be.make_tail(dims[nd], hs[nd], coarsest)
         self._prof = False
 
@@ -336,22 +399,59 @@ class SlabSolver:
         else:
             self.be.launch(op)
 
-    # ---- the cycle -------------------------------------------------------------------
-    def _op(self, Lv, nsweeps, pro_stage=-1, norm_stage=-1, restrict_out=0, zero_in=0, store=1, omega=0.0, v_in=None,
-            v_out=None, coarse=None, coarse_v=None, coarse_f=None, norm_slot=None):
+    # ---- building blocks -----------------------------------------------------------
+    def _range(self, Lv, extra=0, coarse_extra=None):
+        """Local [jlo, jhi) of the columns to produce: the rank's own columns widened by
+        `extra` on each interior side (or, with coarse_extra = e, exactly the fine columns
+        whose restriction gives the rank's own coarse columns widened by e), clipped to the
+        interior columns 1..m-2 of the level."""
+        if coarse_extra is not None:
+            glo, ghi = Lv.b0 + 1 - 2 * coarse_extra, Lv.b1 + 2 * coarse_extra
+            if coarse_extra == 0:
+                glo = Lv.b0
+        else:
+            glo, ghi = Lv.b0 - extra, Lv.b1 + extra
+        glo, ghi = max(glo, 1), min(ghi, Lv.m - 1)
+        return glo - Lv.lo, ghi - Lv.lo
+
+    def _op(self, Lv, nsweeps, jrange, pro_stage=-1, norm_stage=-1, restrict_out=0, zero_in=0, store=1, omega=0.0,
+            v_in=None, v_out=None, coarse=None, coarse_v=None, coarse_f=None, norm_slot=None):
         mc, nccols, gc0 = coarse if coarse is not None else (0, 0, 0)
         return SlabOp(nsweeps=nsweeps, pro_stage=pro_stage, norm_stage=norm_stage, restrict_out=restrict_out,
                       zero_in=zero_in, store=store, v_in=v_in, v_out=v_out, f=Lv.f, coarse_v=coarse_v,
                       coarse_f=coarse_f, norm_slot=norm_slot, m=Lv.m, ncols=Lv.ncols, mc=mc, nccols=nccols,
-                      jlo=Lv.jlo, jhi=Lv.jhi, jfix_lo=Lv.jfix_lo, jfix_hi=Lv.jfix_hi, gf0=Lv.lo, gc0=gc0, dx=Lv.dx,
-                      omega=omega)
+                      jlo=jrange[0], jhi=jrange[1], jfix_lo=Lv.jfix_lo, jfix_hi=Lv.jfix_hi, gf0=Lv.lo, gc0=gc0,
+                      dx=Lv.dx, omega=omega)
+
+    def _halo_ranges(self, Lv, width):
+        """Send/receive column ranges that give each neighbour `width` of the other's own columns."""
+        s_lo = (Lv.o0, Lv.o0 + width) if Lv.lo > 0 else None        # my first own columns -> rank-1
+        r_lo = (Lv.o0 - width, Lv.o0) if Lv.lo > 0 else None        # rank-1's last own columns
+        s_hi = (Lv.o1 - width, Lv.o1) if Lv.hi < Lv.m else None
+        r_hi = (Lv.o1, Lv.o1 + width) if Lv.hi < Lv.m else None
+        return s_lo, r_lo, s_hi, r_hi
+
+    def _xv(self, Lv, width=None):
+        """Exchange item for the live iterate of a level."""
+        return (self.be.comm_tensor(Lv.v[Lv.cur]),) + self._halo_ranges(Lv, Lv.W if width is None else width)
+
+    def _xf(self, Lv, width=None):
+        return (self.be.comm_tensor(Lv.f),) + self._halo_ranges(Lv, Lv.W if width is None else width)
+
+    def _coarse_of(self, l):
+        """(coarse level or None for the tail, (mc, nccols, gc0)) of distributed level l."""
+        if l + 1 < self.ndist:
+            C = self.levels[l + 1]
+            return C, (C.m, C.ncols, C.lo)
+        return None, (self.dims[self.ndist], self.dims[self.ndist], 0)
 
     def _chain(self, level, name, Lv, pro, ns, res, zero_in, omega, coarse=None, coarse_v=None, coarse_f=None,
                norm_slot=None):
-        """[pro] -> ns sweeps -> [res: 1 restrict, 2 norm] as launches of at most SLAB_MAX_SWEEPS
-        sweeps; every launch that stores the iterate flips the level's ping-pong buffers, and
-        between two launches of a chain the halo columns are exchanged."""
+        """[pro] -> ns sweeps -> [res: 1 restrict, 2 norm] on the rank's own columns as launches
+        of at most SLAB_MAX_SWEEPS sweeps; every launch that stores the iterate flips the
+        level's ping-pong buffers, and between two launches of a chain the halo is exchanged."""
         remaining, first = ns, True
+        jr = self._range(Lv)
         while True:
             k = min(remaining, _lib.SLAB_MAX_SWEEPS)
             remaining -= k
@@ -361,7 +461,7 @@ class SlabSolver:
             zi = zero_in if first else 0
             if k > 0 or pr or rs:
                 store = 1 if (k > 0 or pr) else 0
-                op = self._op(Lv, k, pro_stage=0 if pr else -1, norm_stage=k if rs == 2 else -1,
+                op = self._op(Lv, k, jr, pro_stage=0 if pr else -1, norm_stage=k if rs == 2 else -1,
                               restrict_out=1 if rs == 1 else 0, zero_in=zi, store=store, omega=omega,
                               v_in=Lv.v[Lv.cur], v_out=Lv.v[Lv.cur ^ 1], coarse=coarse,
                               coarse_v=coarse_v if pr else None, coarse_f=coarse_f if rs == 1 else None,
@@ -370,53 +470,10 @@ class SlabSolver:
                 if store:
                     Lv.cur ^= 1
                     if not last:
-                        self._exchange_v(Lv)
+                        self.comm.exchange([self._xv(Lv)])
             first = False
             if remaining <= 0:
                 break
-
-    def _halo_ranges(self, Lv):
-        W = self.W
-        s_lo = (Lv.o0, Lv.o0 + W) if Lv.lo > 0 else None            # my first W owned columns -> rank-1
-        r_lo = (Lv.o0 - W, Lv.o0) if Lv.lo > 0 else None            # rank-1's last W owned columns
-        s_hi = (Lv.o1 - W, Lv.o1) if Lv.hi < Lv.m else None
-        r_hi = (Lv.o1, Lv.o1 + W) if Lv.hi < Lv.m else None
-        return s_lo, r_lo, s_hi, r_hi
-
-    def _exchange_v(self, Lv):
-        self.comm.exchange([(self.be.comm_tensor(Lv.v[Lv.cur]),) + self._halo_ranges(Lv)])
-
-    def _coarse_of(self, l):
-        """(coarse level or None for the tail, (mc, nccols, gc0)) of distributed level l."""
-        if l + 1 < self.ndist:
-            C = self.levels[l + 1]
-            return C, (C.m, C.ncols, C.lo)
-        return None, (self.dims[self.ndist], self.dims[self.ndist], 0)
-
-    @staticmethod
-    def _lean(Ndown, Nup):
-        """Few enough sweeps for the byte-saving legs: on levels >= 1 the down leg stores
-        nothing and the up leg recomputes its sweeps from f; on level 0 the up leg of a cycle
-        and the down leg of the next are one launch."""
-        return 1 <= Ndown + Nup <= _lib.SLAB_MAX_SWEEPS
-
-    def _down(self, l, Ndown, Nup, omega):
-        """Down leg of distributed level l (main.cpp:321-327) and the exchanges it implies."""
-        Lv = self.levels[l]
-        C, cshape = self._coarse_of(l)
-        cf = C.f if C is not None else self.tail_f
-        items = []
-        if l >= 1 and (self._lean(Ndown, Nup) or Ndown == 0):
-            # the iterate is zero here: f -> coarse f, nothing stored
-            op = self._op(Lv, Ndown, restrict_out=1, zero_in=1, store=0, omega=omega, coarse=cshape, coarse_f=cf)
-            self._launch(l, "k_stream:down", op)
-        else:
-            self._chain(l, "k_stream:down", Lv, 0, Ndown, 1, 1 if l >= 1 else 0, omega, coarse=cshape, coarse_f=cf)
-            items.append((self.be.comm_tensor(Lv.v[Lv.cur]),) + self._halo_ranges(Lv))
-        if C is not None:
-            items.append((self.be.comm_tensor(C.f),) + self._halo_ranges(C))
-        if items:
-            self.comm.exchange(items)
 
     def _tail(self, Ndown, Nup, omega):
         """All-gather the tail's right-hand side and run the tail on every rank."""
@@ -431,63 +488,134 @@ class SlabSolver:
                     self.tail_f[tb[k]:tb[k + 1]] = allc[k * self.tail_pad:k * self.tail_pad + (tb[k + 1] - tb[k])]
         return self.tail.run(self.tail_f, Ndown, Nup, omega)
 
-    def _up(self, l, Ndown, Nup, omega, vt, norm_slot=None, next_down=False):
-        """Up leg of distributed level l (main.cpp:337-344); on level 0 with the norm of
-        main.cpp:351 and, if next_down, the down leg of the following cycle."""
-        Lv = self.levels[l]
-        C, cshape = self._coarse_of(l)
-        cv = C.v[C.cur] if C is not None else vt
-        items = []
-        if l >= 1 and self._lean(Ndown, Nup):
-            op = self._op(Lv, Ndown + Nup, pro_stage=Ndown, zero_in=1, store=1, omega=omega, v_out=Lv.v[0],
-                          coarse=cshape, coarse_v=cv)
+    # ---- the general schedule: a chain per leg, an exchange after every launch ----------
+    def _cycle_general(self, Ndown, Nup, omega, slot):
+        nd = self.ndist
+        for l in range(nd):  # main.cpp:317-328
+            Lv = self.levels[l]
+            C, cshape = self._coarse_of(l)
+            cf = C.f if C is not None else self.tail_f
+            items = []
+            if l >= 1 and Ndown == 0:
+                # the iterate is zero here: f -> coarse f, nothing stored
+                op = self._op(Lv, 0, self._range(Lv), restrict_out=1, zero_in=1, store=0, omega=omega,
+                              coarse=cshape, coarse_f=cf)
+                self._launch(l, "k_stream:down", op)
+            else:
+                self._chain(l, "k_stream:down", Lv, 0, Ndown, 1, 1 if l >= 1 else 0, omega, coarse=cshape,
+                            coarse_f=cf)
+                items.append(self._xv(Lv))
+            if C is not None:
+                items.append(self._xf(C))
+            if items:
+                self.comm.exchange(items)
+        vt = self._tail(Ndown, Nup, omega)
+        for l in range(nd - 1, -1, -1):  # main.cpp:335-346
+            Lv = self.levels[l]
+            C, cshape = self._coarse_of(l)
+            cv = C.v[C.cur] if C is not None else vt
+            zero_in = 1 if (l >= 1 and Ndown == 0) else 0
+            res = 2 if (l == 0 and slot is not None) else 0
+            self._chain(l, "k_stream:up", Lv, 1, Nup, res, zero_in, omega, coarse=cshape, coarse_v=cv,
+                        norm_slot=slot)
+            self.comm.exchange([self._xv(Lv)])
+
+    # ---- the lean schedule: one exchange and one all-gather per cycle ---------------------
+    def _lean_down0(self, Ndown, omega):
+        """Plain level-0 down leg (first cycle of a call), then the cycle's exchange."""
+        L0 = self.levels[0]
+        C, cshape = self._coarse_of(0)
+        cf = C.f if C is not None else self.tail_f
+        store = 1 if Ndown > 0 else 0
+        op = self._op(L0, Ndown, self._range(L0), restrict_out=1, store=store, omega=omega, v_in=L0.v[L0.cur],
+                      v_out=L0.v[L0.cur ^ 1], coarse=cshape, coarse_f=cf)
+        self._launch(0, "k_stream:down", op)
+        if store:
+            L0.cur ^= 1
+        self._lean_exchange(store)
+
+    def _lean_exchange(self, with_v=True):
+        L0 = self.levels[0]
+        items = [self._xv(L0, self.W0)] if with_v else []
+        if self.ndist >= 2:
+            items.append(self._xf(self.levels[1], self._Ef[1]))
+        if items:
+            self.comm.exchange(items)
+
+    def _lean_coarse(self, Ndown, Nup, omega):
+        """Levels 1..nd-1 down, the tail, levels nd-1..1 up: no communication but the tail's
+        all-gather; halo columns are recomputed."""
+        nd = self.ndist
+        Ev, Ef = self._Ev, self._Ef
+        for l in range(1, nd):
+            Lv = self.levels[l]
+            C, cshape = self._coarse_of(l)
+            cf = C.f if C is not None else self.tail_f
+            jr = self._range(Lv, coarse_extra=Ef[l + 1] if l + 1 < nd else 0)
+            op = self._op(Lv, Ndown, jr, restrict_out=1, zero_in=1, store=0, omega=omega, coarse=cshape, coarse_f=cf)
+            self._launch(l, "k_stream:down", op)
+        vt = self._tail(Ndown, Nup, omega)
+        for l in range(nd - 1, 0, -1):
+            Lv = self.levels[l]
+            C, cshape = self._coarse_of(l)
+            cv = C.v[C.cur] if C is not None else vt
+            op = self._op(Lv, Ndown + Nup, self._range(Lv, extra=Ev[l]), pro_stage=Ndown, zero_in=1, store=1,
+                          omega=omega, v_out=Lv.v[0], coarse=cshape, coarse_v=cv)
             Lv.cur = 0
             self._launch(l, "k_stream:up", op)
-        elif l >= 1 and Ndown == 0:
-            self._chain(l, "k_stream:up", Lv, 1, Nup, 0, 1, omega, coarse=cshape, coarse_v=cv)
-        elif next_down:
+        return vt
+
+    def _lean_up0(self, Ndown, Nup, omega, vt, slot, next_down):
+        """Level-0 up leg with the cycle's residual norm; with next_down also the down leg
+        of the following cycle (one launch), then that cycle's exchange."""
+        L0 = self.levels[0]
+        C, cshape = self._coarse_of(0)
+        cv = C.v[C.cur] if C is not None else vt
+        if next_down:
             cf = C.f if C is not None else self.tail_f
-            op = self._op(Lv, Nup + Ndown, pro_stage=0, norm_stage=Nup, restrict_out=1, store=1, omega=omega,
-                          v_in=Lv.v[Lv.cur], v_out=Lv.v[Lv.cur ^ 1], coarse=cshape, coarse_v=cv, coarse_f=cf,
-                          norm_slot=norm_slot)
-            Lv.cur ^= 1
-            self._launch(l, "k_stream:updown", op)
-            if C is not None:
-                items.append((self.be.comm_tensor(C.f),) + self._halo_ranges(C))
+            op = self._op(L0, Nup + Ndown, self._range(L0), pro_stage=0, norm_stage=Nup, restrict_out=1, store=1,
+                          omega=omega, v_in=L0.v[L0.cur], v_out=L0.v[L0.cur ^ 1], coarse=cshape, coarse_v=cv,
+                          coarse_f=cf, norm_slot=slot)
+            self._launch(0, "k_stream:updown", op)
+            L0.cur ^= 1
+            self._lean_exchange(True)
         else:
-            self._chain(l, "k_stream:up", Lv, 1, Nup, 2 if norm_slot is not None else 0, 0, omega, coarse=cshape,
-                        coarse_v=cv, norm_slot=norm_slot)
-        items.append((self.be.comm_tensor(Lv.v[Lv.cur]),) + self._halo_ranges(Lv))
-        self.comm.exchange(items)
+            op = self._op(L0, Nup, self._range(L0), pro_stage=0, norm_stage=Nup, store=1, omega=omega,
+                          v_in=L0.v[L0.cur], v_out=L0.v[L0.cur ^ 1], coarse=cshape, coarse_v=cv, norm_slot=slot)
+            self._launch(0, "k_stream:up", op)
+            L0.cur ^= 1
+            self.comm.exchange([self._xv(L0, self.W0)])
 
     def cycles(self, Nv, Ndown, Nup, omega, pureJacobi=False):
         """Nv cycles (main.cpp:309-354).  Returns MGOutputs; Times is the cumulative wall
         time of the cycles on this rank (a host clock: exchanges are part of a cycle)."""
-        import time
         be = self.be
         slots = be.slots(Nv + 1)
         L0 = self.levels[0]
-        nd = self.ndist
-        lean = self._lean(Ndown, Nup)
+        lean = 1 <= Ndown + Nup <= MAX_LEAN and not pureJacobi
+        if lean:
+            self._Ev, self._Ef = halo_plan(self.ndist, Ndown, Nup)
+            for l in range(1, self.ndist):
+                if max(self._Ef[l], self._Ev[l]) > self.levels[l].W:
+                    raise RuntimeError("level %d halo %d exceeds the allocated %d" %
+                                       (l, max(self._Ef[l], self._Ev[l]), self.levels[l].W))
         # main.cpp:307: the norm of the initial residual (halo columns of v must be current)
-        self._exchange_v(L0)
+        self.comm.exchange([self._xv(L0, self.W0)])
         self._chain(0, "k_stream:norm", L0, 0, 0, 2, 0, omega, norm_slot=be.slot_ptr(slots, 0))
         times = np.zeros(Nv + 1)
         for it in range(Nv):
             t0 = time.perf_counter()
             slot = be.slot_ptr(slots, it + 1)
-            if not pureJacobi:
-                if it == 0 or not lean:  # otherwise the previous cycle's level-0 launch did it
-                    self._down(0, Ndown, Nup, omega)
-                for l in range(1, nd):  # main.cpp:317-328
-                    self._down(l, Ndown, Nup, omega)
-                vt = self._tail(Ndown, Nup, omega)
-                for l in range(nd - 1, 0, -1):  # main.cpp:335-346
-                    self._up(l, Ndown, Nup, omega, vt)
-                self._up(0, Ndown, Nup, omega, vt, norm_slot=slot, next_down=lean and it + 1 < Nv)
-            else:  # main.cpp:348 and :351 in one pass
+            if pureJacobi:  # main.cpp:348 and :351 in one pass
                 self._chain(0, "k_stream:up", L0, 0, 1, 2, 0, omega, norm_slot=slot)
-                self._exchange_v(L0)
+                self.comm.exchange([self._xv(L0, self.W0)])
+            elif lean:
+                if it == 0:  # later cycles: the previous cycle's level-0 launch did the down leg
+                    self._lean_down0(Ndown, omega)
+                vt = self._lean_coarse(Ndown, Nup, omega)
+                self._lean_up0(Ndown, Nup, omega, vt, slot, next_down=it + 1 < Nv)
+            else:
+                self._cycle_general(Ndown, Nup, omega, slot)
             times[it + 1] = times[it] + (time.perf_counter() - t0)
         self.comm.allreduce_max_(slots)
         be.synchronize()

@@ -39,7 +39,7 @@ def test_slab_random_rhs_generator(mg):
     assert_bits(edge, np.ascontiguousarray(full.T), "random_torch_cols full")
 
 
-@pytest.mark.parametrize("world,M,tail_m", [(2, 513, 65), (3, 1025, 129), (4, 2049, 257)])
+@pytest.mark.parametrize("world,M,tail_m", [(2, 513, 65), (3, 1025, 129), (4, 2049, 257), (2, 1025, 65)])
 def test_ranks_share_gpu_over_gloo(O, world, M, tail_m):
     codes, outs = run_ranks(world, ["hip", M, 3, 2, 2, 0.6, tail_m, 0], timeout=400)
     assert codes == [0] * world, "\n".join(outs)

@@ -67,7 +67,26 @@ def test_numpy_backend_single_slab_matches_oracle(O):
         assert_bits(sol, ref_sol, "Sol V(%d,%d)" % (nd, nu))
 
 
-@pytest.mark.parametrize("world,M,tail_m", [(2, 129, 33), (3, 257, 33), (4, 257, 65), (2, 65, 33)])
+def test_lean_schedule_exchanges_once_per_cycle(O):
+    """With Ndown+Nup <= 4 a cycle costs ONE neighbour exchange (level-0 iterate + level-1
+    right-hand side); the coarser distributed levels recompute their halo columns."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from slab_numpy_backend import NumpyBackend
+    from multigrid_amd import rhs, slab
+    M = 129
+    S = slab.SlabSolver(M, 1.0 / (M - 1), 2, backend=NumpyBackend(O), tail_m=17)
+    assert S.ndist == 3
+    S.set_problem(rhs.random_np(M), np.zeros((M, M), order="F"))
+    S.cycles(4, 2, 2, 0.6)
+    assert S.comm.nexchanges == 1 + 1 + 4  # initial norm, first down leg, one per cycle
+    S.comm.nexchanges = 0
+    S.cycles(2, 3, 3, 0.6)                   # not lean: an exchange after every launch
+    assert S.comm.nexchanges > 2 * 3
+    assert slab.halo_plan(3, 2, 2) == ([0, 4, 4, 0], [0, 20, 8, 0])
+    S.close()
+
+
+@pytest.mark.parametrize("world,M,tail_m", [(2, 129, 33), (3, 257, 33), (4, 257, 65), (2, 65, 33), (2, 513, 33)])
 def test_gloo_ranks_match_oracle(O, world, M, tail_m):
     codes, outs = run_ranks(world, ["numpy", M, 3, 2, 2, 0.6, tail_m, 0])
     assert codes == [0] * world, "\n".join(outs)
@@ -76,7 +95,9 @@ def test_gloo_ranks_match_oracle(O, world, M, tail_m):
 
 def test_gloo_other_sweep_counts_and_pure_jacobi(O):
     for args in (["numpy", 129, 2, 5, 6, 0.8, 33, 0], ["numpy", 129, 2, 0, 2, 0.6, 33, 0],
-                 ["numpy", 129, 3, 2, 2, 0.6, 33, 1]):
+                 ["numpy", 129, 3, 2, 2, 0.6, 33, 1], ["numpy", 129, 3, 1, 2, 0.7, 17, 0],
+                 ["numpy", 129, 2, 3, 1, 0.6, 17, 0], ["numpy", 129, 2, 4, 0, 0.6, 17, 0],
+                 ["numpy", 129, 2, 0, 0, 0.6, 33, 0]):
         codes, outs = run_ranks(2, args)
         assert codes == [0, 0], "\n".join(outs)
 
