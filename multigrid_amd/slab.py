@@ -30,6 +30,7 @@ HipBackend (libmgx's mgx_slab_launch / mgx_plan_vcycle_async); tests inject a
 CPU backend to exercise this driver under gloo without a GPU.
 """
 import ctypes
+import os
 import time
 
 import numpy as np
@@ -159,9 +160,14 @@ class _Comm:
     def exchange(self, items):
         """items: list of (tensor, send_lo, recv_lo, send_hi, recv_hi) where each entry but
         the tensor is a (start, stop) row range or None.  *_lo talk to rank-1, *_hi to rank+1."""
+        self.exchange_finish(self.exchange_start(items))
+
+    def exchange_start(self, items):
+        """Post the sends and receives of exchange(items); they run beside whatever is
+        launched next on the compute stream.  Returns a handle for exchange_finish()."""
         self.nexchanges += 1
         if self.size == 1:
-            return
+            return None
         ops, copies = [], []
         for idx, (t, s_lo, r_lo, s_hi, r_hi) in enumerate(items):
             for (rng, peer, is_send, side) in ((r_lo, self.rank - 1, False, 0), (r_hi, self.rank + 1, False, 1),
@@ -185,6 +191,13 @@ class _Comm:
                                            in ops])
         else:
             reqs = [fn(buf, self._global(peer), group=self.group, tag=tag) for (fn, buf, peer, tag) in ops]
+        return reqs, copies
+
+    def exchange_finish(self, handle):
+        """Make the compute stream (and, for gloo, the host) wait for a posted exchange."""
+        if handle is None:
+            return
+        reqs, copies = handle
         for r in reqs:
             r.wait()
         for view, buf in copies:
@@ -335,6 +348,8 @@ class SlabSolver:
         self.tail_f = self.be.zeros(dims[nd], dims[nd])
         self.tail = self.be.make_tail(dims[nd], hs[nd], coarsest)
         self._prof = False
+        # post the level-0 halo exchange between the edge columns and the interior columns
+        self.overlap = os.environ.get("MGX_SLAB_OVERLAP", "1") != "0"
 
     # ---- data in / out ---------------------------------------------------------
     def set_problem(self, f_global, v_global):
@@ -381,6 +396,7 @@ class SlabSolver:
         self._prof = bool(enable)
         self._prof_recs = []
         self._prof_tot = {}
+        self._prof_pts = {}
 
     def profile_totals(self):
         for name, a, b in getattr(self, "_prof_recs", []):
@@ -389,6 +405,10 @@ class SlabSolver:
         self._prof_recs = []
         return dict(getattr(self, "_prof_tot", {}))
 
+    def profile_points(self):
+        """{kernel name: grid points produced by its timed launches} since profile(True)."""
+        return dict(getattr(self, "_prof_pts", {}))
+
     def _launch(self, level, name, op):
         if self._prof and level == 0 and self.be.name == "hip":
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -396,8 +416,46 @@ class SlabSolver:
             self.be.launch(op)
             b.record()
             self._prof_recs.append((name, a, b))
+            self._prof_pts[name] = self._prof_pts.get(name, 0) + (op.jhi - op.jlo) * op.m
         else:
             self.be.launch(op)
+
+    def _launch_level0(self, name, make_op, items_after, flip):
+        """A level-0 launch in up to three parts, so that the halo exchange that follows it
+        overlaps most of it: the columns the neighbours are waiting for first, then the
+        exchange is posted, then the interior columns, then the exchange is awaited.
+        make_op(jrange) builds the launch for a column range; items_after() lists what to
+        exchange (called after the parts that produce it are enqueued)."""
+        L0 = self.levels[0]
+        jlo, jhi = self._range(L0)
+        ef1 = self._Ef[1] if (self.ndist >= 2 and getattr(self, "_Ef", None)) else 0
+        B = max(2 * ef1, self.W0)
+        B += B & 1
+        lo_nb, hi_nb = L0.lo > 0, L0.hi < L0.m
+        ilo, ihi = jlo, jhi
+        edges = []
+        if self.overlap and (lo_nb or hi_nb) and (jhi - jlo) >= 4 * B:
+            if lo_nb:
+                edges.append((jlo, jlo + B))
+                ilo = jlo + B
+            if hi_nb:
+                edges.append((jhi - B, jhi))
+                ihi = jhi - B
+        ops = [make_op(r) for r in edges]
+        interior = make_op((ilo, ihi))  # built before the flip: it names the buffers explicitly
+        for op in ops:
+            self._launch(0, "k_stream:edge", op)
+        if flip:
+            L0.cur ^= 1                 # from here on v[cur] is the buffer being written
+        if edges:
+            handle = self.comm.exchange_start(items_after())
+            self._launch(0, name, interior)
+            self.comm.exchange_finish(handle)
+        else:
+            self._launch(0, name, interior)
+            items = items_after()
+            if items:
+                self.comm.exchange(items)
 
     # ---- building blocks -----------------------------------------------------------
     def _range(self, Lv, extra=0, coarse_extra=None):
@@ -521,26 +579,27 @@ class SlabSolver:
             self.comm.exchange([self._xv(Lv)])
 
     # ---- the lean schedule: one exchange and one all-gather per cycle ---------------------
+    def _lean_items(self, with_v=True):
+        """What a lean cycle exchanges: the level-0 iterate and the level-1 right-hand side."""
+        L0 = self.levels[0]
+        items = [self._xv(L0, self.W0)] if with_v else []
+        if self.ndist >= 2:
+            items.append(self._xf(self.levels[1], self._Ef[1]))
+        return items
+
     def _lean_down0(self, Ndown, omega):
         """Plain level-0 down leg (first cycle of a call), then the cycle's exchange."""
         L0 = self.levels[0]
         C, cshape = self._coarse_of(0)
         cf = C.f if C is not None else self.tail_f
         store = 1 if Ndown > 0 else 0
-        op = self._op(L0, Ndown, self._range(L0), restrict_out=1, store=store, omega=omega, v_in=L0.v[L0.cur],
-                      v_out=L0.v[L0.cur ^ 1], coarse=cshape, coarse_f=cf)
-        self._launch(0, "k_stream:down", op)
-        if store:
-            L0.cur ^= 1
-        self._lean_exchange(store)
+        vin, vout = L0.v[L0.cur], L0.v[L0.cur ^ 1]
 
-    def _lean_exchange(self, with_v=True):
-        L0 = self.levels[0]
-        items = [self._xv(L0, self.W0)] if with_v else []
-        if self.ndist >= 2:
-            items.append(self._xf(self.levels[1], self._Ef[1]))
-        if items:
-            self.comm.exchange(items)
+        def make_op(jr):
+            return self._op(L0, Ndown, jr, restrict_out=1, store=store, omega=omega, v_in=vin, v_out=vout,
+                            coarse=cshape, coarse_f=cf)
+
+        self._launch_level0("k_stream:down", make_op, lambda: self._lean_items(bool(store)), flip=bool(store))
 
     def _lean_coarse(self, Ndown, Nup, omega):
         """Levels 1..nd-1 down, the tail, levels nd-1..1 up: no communication but the tail's
@@ -571,20 +630,21 @@ class SlabSolver:
         L0 = self.levels[0]
         C, cshape = self._coarse_of(0)
         cv = C.v[C.cur] if C is not None else vt
+        cf = C.f if C is not None else self.tail_f
+        vin, vout = L0.v[L0.cur], L0.v[L0.cur ^ 1]
         if next_down:
-            cf = C.f if C is not None else self.tail_f
-            op = self._op(L0, Nup + Ndown, self._range(L0), pro_stage=0, norm_stage=Nup, restrict_out=1, store=1,
-                          omega=omega, v_in=L0.v[L0.cur], v_out=L0.v[L0.cur ^ 1], coarse=cshape, coarse_v=cv,
-                          coarse_f=cf, norm_slot=slot)
-            self._launch(0, "k_stream:updown", op)
-            L0.cur ^= 1
-            self._lean_exchange(True)
+            def make_op(jr):
+                return self._op(L0, Nup + Ndown, jr, pro_stage=0, norm_stage=Nup, restrict_out=1, store=1,
+                                omega=omega, v_in=vin, v_out=vout, coarse=cshape, coarse_v=cv, coarse_f=cf,
+                                norm_slot=slot)
+
+            self._launch_level0("k_stream:updown", make_op, lambda: self._lean_items(True), flip=True)
         else:
-            op = self._op(L0, Nup, self._range(L0), pro_stage=0, norm_stage=Nup, store=1, omega=omega,
-                          v_in=L0.v[L0.cur], v_out=L0.v[L0.cur ^ 1], coarse=cshape, coarse_v=cv, norm_slot=slot)
-            self._launch(0, "k_stream:up", op)
-            L0.cur ^= 1
-            self.comm.exchange([self._xv(L0, self.W0)])
+            def make_op(jr):
+                return self._op(L0, Nup, jr, pro_stage=0, norm_stage=Nup, store=1, omega=omega, v_in=vin,
+                                v_out=vout, coarse=cshape, coarse_v=cv, norm_slot=slot)
+
+            self._launch_level0("k_stream:up", make_op, lambda: [self._xv(L0, self.W0)], flip=True)
 
     def cycles(self, Nv, Ndown, Nup, omega, pureJacobi=False):
         """Nv cycles (main.cpp:309-354).  Returns MGOutputs; Times is the cumulative wall

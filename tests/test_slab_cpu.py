@@ -86,7 +86,8 @@ def test_lean_schedule_exchanges_once_per_cycle(O):
     S.close()
 
 
-@pytest.mark.parametrize("world,M,tail_m", [(2, 129, 33), (3, 257, 33), (4, 257, 65), (2, 65, 33), (2, 513, 33)])
+@pytest.mark.parametrize("world,M,tail_m", [(2, 129, 33), (3, 257, 33), (4, 257, 65), (2, 65, 33), (2, 513, 33),
+                                            (2, 513, 129), (3, 513, 65)])
 def test_gloo_ranks_match_oracle(O, world, M, tail_m):
     codes, outs = run_ranks(world, ["numpy", M, 3, 2, 2, 0.6, tail_m, 0])
     assert codes == [0] * world, "\n".join(outs)
