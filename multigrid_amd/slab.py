@@ -79,6 +79,12 @@ class HipBackend:
     def comm_tensor(self, t):
         return t
 
+    def index_array(self, rows):
+        return torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(self.device)
+
+    def take_rows(self, src, rows, out):
+        torch.index_select(src, 0, rows, out=out)
+
     def launch(self, op):
         o = _lib.mgx_slab_op()
         o.struct_size = ctypes.sizeof(_lib.mgx_slab_op)
@@ -112,6 +118,21 @@ class HipBackend:
         torch.cuda.current_stream().synchronize()
 
 
+class _DevicePointer:
+    """Adapter that lets torch wrap device memory owned by libmgx (a plan's level-0 arrays)
+    as a tensor without copying."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _device_view(ptr, m, device):
+    if not ptr:
+        raise RuntimeError("libmgx returned a null device pointer")
+    return torch.as_tensor(_DevicePointer(ptr, (m, m)), device=device)
+
+
 class _HipTail:
     """The replicated coarse tail: a single-GPU plan of the tail's finest level."""
 
@@ -122,14 +143,15 @@ class _HipTail:
         opt = _lib.make_options(device=torch.cuda.current_device(), stream=torch.cuda.current_stream().cuda_stream,
                                 schedule=be.schedule)
         _lib.check(be.L.mgx_plan_create(ctypes.byref(self.h), m, dx, coarsest, ctypes.byref(opt)))
-        self.v = be.zeros(m, m)
+        # the plan's own fine-level buffers as tensors (no copies in or out):
+        # row k of the tensor is column k of the level
+        self.f = _device_view(be.L.mgx_plan_f_dev(self.h), m, be.device)
+        self.v = _device_view(be.L.mgx_plan_v_dev(self.h), m, be.device)
 
-    def run(self, f_full, Ndown, Nup, omega):
-        """v = one V(Ndown,Nup) cycle from a zero guess for the right-hand side f_full."""
-        L = self.be.L
-        _lib.check(L.mgx_plan_set_dev(self.h, f_full.data_ptr(), None))
-        _lib.check(L.mgx_plan_vcycle_async(self.h, Ndown, Nup, omega, 1))
-        _lib.check(L.mgx_plan_get_dev(self.h, self.v.data_ptr()))
+    def run(self, Ndown, Nup, omega):
+        """One V(Ndown,Nup) cycle from a zero guess for the right-hand side in self.f;
+        returns the iterate (self.v).  Asynchronous on the current stream."""
+        _lib.check(self.be.L.mgx_plan_vcycle_async(self.h, Ndown, Nup, omega, 1))
         return self.v
 
     def close(self):
@@ -203,15 +225,24 @@ class _Comm:
         for view, buf in copies:
             view.copy_(buf)
 
-    def allgather(self, t):
-        """Concatenation over ranks of equally shaped tensors along dim 0."""
+    def allgather(self, t, out=None):
+        """Concatenation over ranks of equally shaped tensors along dim 0 (into `out` if given)."""
         self.ngathers += 1
         if self.size == 1:
+            if out is not None:
+                out.copy_(t)
+                return out
             return t
         src = self._stage(t).contiguous()
-        out = torch.empty((self.size * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-        dist.all_gather(list(out.chunk(self.size, 0)), src, group=self.group)
-        return out.to(t.device) if out.device != t.device else out
+        staged = out is None or out.device != src.device
+        buf = torch.empty((self.size * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype,
+                          device=src.device) if staged else out
+        dist.all_gather(list(buf.chunk(self.size, 0)), src, group=self.group)
+        if out is None:
+            return buf.to(t.device) if buf.device != t.device else buf
+        if staged:
+            out.copy_(buf)
+        return out
 
     def allreduce_max_(self, t):
         if self.size == 1:
@@ -342,11 +373,21 @@ class SlabSolver:
             Lv.cur = 0
             self.levels.append(Lv)
         # the tail's top level: the coarse columns this rank produces, padded to a common count
-        self.tail_b = bounds[nd]
-        self.tail_pad = max(bounds[nd][k + 1] - bounds[nd][k] for k in range(R))
-        self.tail_send = self.be.zeros(self.tail_pad, dims[nd])
-        self.tail_f = self.be.zeros(dims[nd], dims[nd])
+        # Every rank contributes `pad` consecutive columns of the tail's right-hand side
+        # (its own, plus at most a few of a neighbour's that the receiver ignores), so the
+        # all-gather needs no packing; one indexed copy puts the owners' columns in place.
         self.tail = self.be.make_tail(dims[nd], hs[nd], coarsest)
+        self.tail_f = self.tail.f  # the tail plan's own right-hand side buffer (mt x mt)
+        tb = bounds[nd]
+        pad = max(tb[k + 1] - tb[k] for k in range(R))
+        self.tail_pad = pad
+        self.tail_start = [min(tb[k], mt - pad) for k in range(R)]
+        rows = np.empty(mt, dtype=np.int64)
+        for k in range(R):
+            for j in range(tb[k], tb[k + 1]):
+                rows[j] = k * pad + (j - self.tail_start[k])
+        self.tail_rows = self.be.index_array(rows)
+        self.tail_gathered = self.be.zeros(R * pad, mt) if R > 1 else None
         self._prof = False
         # post the level-0 halo exchange between the edge columns and the interior columns
         self.overlap = os.environ.get("MGX_SLAB_OVERLAP", "1") != "0"
@@ -536,15 +577,12 @@ class SlabSolver:
     def _tail(self, Ndown, Nup, omega):
         """All-gather the tail's right-hand side and run the tail on every rank."""
         R, g = self.comm.size, self.comm.rank
-        tb = self.tail_b
         if R > 1:
-            n_own = tb[g + 1] - tb[g]
-            self.tail_send[:n_own] = self.tail_f[tb[g]:tb[g + 1]]
-            allc = self.comm.allgather(self.be.comm_tensor(self.tail_send))
-            for k in range(R):
-                if k != g:
-                    self.tail_f[tb[k]:tb[k + 1]] = allc[k * self.tail_pad:k * self.tail_pad + (tb[k + 1] - tb[k])]
-        return self.tail.run(self.tail_f, Ndown, Nup, omega)
+            s = self.tail_start[g]
+            mine = self.tail_f[s:s + self.tail_pad]
+            self.comm.allgather(self.be.comm_tensor(mine), out=self.be.comm_tensor(self.tail_gathered))
+            self.be.take_rows(self.tail_gathered, self.tail_rows, out=self.tail_f)
+        return self.tail.run(Ndown, Nup, omega)
 
     # ---- the general schedule: a chain per leg, an exchange after every launch ----------
     def _cycle_general(self, Ndown, Nup, omega, slot):

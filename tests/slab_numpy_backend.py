@@ -68,6 +68,12 @@ class NumpyBackend:
     def comm_tensor(self, t):
         return torch.from_numpy(t) if isinstance(t, np.ndarray) else t
 
+    def index_array(self, rows):
+        return np.asarray(rows, dtype=np.int64)
+
+    def take_rows(self, src, rows, out):
+        out[:] = np.asarray(src)[rows]
+
     def slot_ptr(self, slots, k):
         return (slots, k)
 
@@ -158,12 +164,15 @@ class NumpyBackend:
 class _OracleTail:
     def __init__(self, O, m, dx, coarsest):
         self.O, self.m, self.dx, self.coarsest = O, m, dx, coarsest
+        self.f = np.zeros((m, m))  # slab layout: row k = column k
+        self.v = np.zeros((m, m))
 
-    def run(self, f_full, Ndown, Nup, omega):
-        f = np.asfortranarray(np.asarray(f_full).T)
+    def run(self, Ndown, Nup, omega):
+        f = np.asfortranarray(self.f.T)
         sol, _, _ = self.O.multigrid(f, np.zeros((self.m, self.m), order="F"), self.dx, 1, Ndown, Nup, omega,
                                      self.coarsest)
-        return np.ascontiguousarray(sol.T)
+        self.v[:] = sol.T
+        return self.v
 
     def close(self):
         pass
