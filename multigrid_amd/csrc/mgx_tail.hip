@@ -8,31 +8,42 @@
 // one doubles as the residual), 3*8*(65^2+33^2+17^2+9^2+5^2+3^2) = 137 KB of
 // the CU's 160 KB.  The top level's f is read from HBM once and its final v is
 // written once; everything in between is LDS traffic separated by workgroup
-// barriers.  Arrays are column-major with odd leading dimension, so lanes
-// running along i hit distinct banks.
+// barriers.  Lane t of wave w handles rows 1+t, 65+t, ... of columns 1+w,
+// 17+w, ...: arrays are column-major with odd leading dimension, so the 64
+// lanes of a wave hit distinct banks, and no index needs a division.
 //
-// The top level starts from a zero iterate, as every coarse level does when the
-// down sweep reaches it (main.cpp:295-299,345).  Expressions are those of
-// mgx_kernels.hip, evaluated in the same order: identical bits.
+// The levels are walked by a compile-time recursion so that each level's
+// pointers and sizes live in registers.  The top level starts from a zero
+// iterate, as every coarse level does when the down sweep reaches it
+// (main.cpp:295-299,345).  Expressions are those of mgx_kernels.hip, evaluated
+// in the same order: identical bits.
 #include "mgx_internal.h"
 
 namespace mgx {
 
 namespace {
 
+// u is the live iterate, w the idle array of the ping-pong pair.  (Two named
+// pointers that are swapped, not an array indexed by a run-time "current"
+// index: that would put the view in private memory.)
 struct LevelView {
-    double *f, *v[2];
-    int m, cur;
+    double *f, *u, *w;
+    int m;
     double h2, invh2;
 };
 
-__device__ __forceinline__ void tail_sweep(LevelView &L, double omega, double nomega, int tid, int nt)
+// interior points (i, j), 1 <= i, j <= m-2, dealt over the workgroup
+#define MGX_TAIL_FOR_INTERIOR(m_, i_, j_)                                  \
+    for (int j_ = 1 + (int)(threadIdx.x >> 6); j_ < (m_)-1; j_ += 16)      \
+        for (int i_ = 1 + (int)(threadIdx.x & 63); i_ < (m_)-1; i_ += 64)
+
+__device__ __forceinline__ void tail_sweep(LevelView &L, double omega, double nomega)
 {
-    const int m = L.m, mi = m - 2;
-    const double *__restrict__ u = L.v[L.cur];
-    double *__restrict__ o = L.v[L.cur ^ 1];
-    for (int k = tid; k < mi * mi; k += nt) {
-        const int j = 1 + k / mi, i = 1 + k - (j - 1) * mi;
+    const int m = L.m;
+    const double *__restrict__ u = L.u;
+    double *__restrict__ o = L.w;
+    MGX_TAIL_FOR_INTERIOR(m, i, j)
+    {
         const int x = i + j * m;
         double s = u[x - 1] + u[x + 1];  // main.cpp:194-195
         s = s + u[x - m];
@@ -43,17 +54,19 @@ __device__ __forceinline__ void tail_sweep(LevelView &L, double omega, double no
         o[x] = u[x] * nomega + s;
     }
     __syncthreads();
-    L.cur ^= 1;
+    double *t = L.u;
+    L.u = L.w;
+    L.w = t;
 }
 
 // residual of the live iterate into the idle v array (its boundary is zero)
-__device__ __forceinline__ void tail_residual(const LevelView &L, int tid, int nt)
+__device__ __forceinline__ void tail_residual(const LevelView &L)
 {
-    const int m = L.m, mi = m - 2;
-    const double *__restrict__ u = L.v[L.cur];
-    double *__restrict__ r = L.v[L.cur ^ 1];
-    for (int k = tid; k < mi * mi; k += nt) {
-        const int j = 1 + k / mi, i = 1 + k - (j - 1) * mi;
+    const int m = L.m;
+    const double *__restrict__ u = L.u;
+    double *__restrict__ r = L.w;
+    MGX_TAIL_FOR_INTERIOR(m, i, j)
+    {
         const int x = i + j * m;
         double s = u[x - 1] + u[x + 1];  // main.cpp:277
         s = s + u[x - m];
@@ -65,12 +78,12 @@ __device__ __forceinline__ void tail_residual(const LevelView &L, int tid, int n
     __syncthreads();
 }
 
-__device__ __forceinline__ void tail_restrict(const LevelView &F, LevelView &C, int tid, int nt)
+__device__ __forceinline__ void tail_restrict(const LevelView &F, const LevelView &C)
 {
-    const int mf = F.m, mc = C.m, mi = mc - 2;
-    const double *__restrict__ r = F.v[F.cur ^ 1];
-    for (int k = tid; k < mi * mi; k += nt) {
-        const int J = 1 + k / mi, I = 1 + k - (J - 1) * mi;
+    const int mf = F.m, mc = C.m;
+    const double *__restrict__ r = F.w;
+    MGX_TAIL_FOR_INTERIOR(mc, I, J)
+    {
         const int x = 2 * I + 2 * J * mf;
         const double a = r[x] * 0.25;  // main.cpp:216-218, corner quirk included
         double nb = r[x - 1] + r[x + 1];
@@ -86,13 +99,13 @@ __device__ __forceinline__ void tail_restrict(const LevelView &F, LevelView &C, 
     __syncthreads();
 }
 
-__device__ __forceinline__ void tail_prolong_add(LevelView &F, const LevelView &C, int tid, int nt)
+__device__ __forceinline__ void tail_prolong_add(const LevelView &F, const LevelView &C)
 {
-    const int mf = F.m, mc = C.m, mi = mf - 2;
-    const double *__restrict__ c = C.v[C.cur];
-    double *__restrict__ u = F.v[F.cur];
-    for (int k = tid; k < mi * mi; k += nt) {
-        const int j = 1 + k / mi, i = 1 + k - (j - 1) * mi;
+    const int mf = F.m, mc = C.m;
+    const double *__restrict__ c = C.u;
+    double *__restrict__ u = F.u;
+    MGX_TAIL_FOR_INTERIOR(mf, i, j)
+    {
         const int y = (i >> 1) + (j >> 1) * mc;
         const bool io = i & 1, jo = j & 1;
         double p;  // main.cpp:234-246
@@ -113,73 +126,75 @@ __device__ __forceinline__ void tail_prolong_add(LevelView &F, const LevelView &
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_tail(const TailArgs A)
+// l is a compile-time index: a run-time index into the kernel-argument arrays would
+// force the whole argument block into private (scratch) memory
+template <int l>
+__device__ __forceinline__ LevelView tail_view(const TailArgs &A, double *lds, int off)
 {
-    extern __shared__ __align__(16) double lds[];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    LevelView L[TAIL_MAX_LEVELS];
-    int total = 0;
-#pragma unroll
-    for (int l = 0; l < TAIL_MAX_LEVELS; l++) {
-        if (l < A.nlev) {
-            const int n = A.m[l] * A.m[l];
-            L[l].f = lds + total;
-            L[l].v[0] = lds + total + n;
-            L[l].v[1] = lds + total + 2 * n;
-            L[l].m = A.m[l];
-            L[l].cur = 0;
-            L[l].h2 = A.h2[l];
-            L[l].invh2 = A.invh2[l];
-            total += 3 * n;
-        }
-    }
-    for (int k = tid; k < total; k += nt) lds[k] = 0.0;  // main.cpp:295-299
-    __syncthreads();
-    {
-        const int m0 = A.m[0];
-        for (int k = tid; k < m0 * m0; k += nt) {
-            const int j = k / m0, i = k - j * m0;
-            L[0].f[k] = A.f[(size_t)i + (size_t)j * (size_t)A.ld];
-        }
-    }
-    __syncthreads();
-    const double omega = A.omega, nomega = A.nomega;
-#pragma unroll
-    for (int l = 0; l < TAIL_MAX_LEVELS - 1; l++) {  // main.cpp:317-328
-        if (l < A.nlev - 1) {
-            for (int it = 0; it < A.Ndown; it++) tail_sweep(L[l], omega, nomega, tid, nt);
-            tail_residual(L[l], tid, nt);
-            tail_restrict(L[l], L[l + 1], tid, nt);
-        }
-    }
-#pragma unroll
-    for (int l = 0; l < TAIL_MAX_LEVELS; l++) {  // main.cpp:331
-        if (l == A.nlev - 1 && L[l].m == 3) {
-            if (tid == 0) {
-                double *u = L[l].v[L[l].cur];
+    LevelView L;
+    const int n = A.m[l] * A.m[l];
+    L.f = lds + off;
+    L.u = lds + off + n;
+    L.w = lds + off + 2 * n;
+    L.m = A.m[l];
+    L.h2 = A.h2[l];
+    L.invh2 = A.invh2[l];
+    return L;
+}
+
+// Level l (whose f is in place and whose iterate is zero) and everything below
+// it: down leg, recursion, up leg.  Returns with L.u naming the final iterate.
+template <int l>
+__device__ __forceinline__ void tail_level(const TailArgs &A, double *lds, int off, LevelView &L)
+{
+    if (l == A.nlev - 1) {  // main.cpp:331
+        if (L.m == 3) {
+            if (threadIdx.x == 0) {
+                double *u = L.u;
                 double s = u[0 + 1 * 3] + u[2 + 1 * 3];
                 s = s + u[1 + 0 * 3];
                 s = s + u[1 + 2 * 3];
-                s = s - L[l].f[1 + 1 * 3] * L[l].h2;
+                s = s - L.f[1 + 1 * 3] * L.h2;
                 u[1 + 1 * 3] = s * 0.25;
             }
             __syncthreads();
         }
+        return;
     }
+    if constexpr (l + 1 < TAIL_MAX_LEVELS) {
+        for (int it = 0; it < A.Ndown; it++) tail_sweep(L, A.omega, A.nomega);  // main.cpp:321
+        tail_residual(L);                                                       // main.cpp:325
+        const int offc = off + 3 * L.m * L.m;
+        LevelView C = tail_view<l + 1>(A, lds, offc);
+        tail_restrict(L, C);                                                    // main.cpp:327
+        tail_level<l + 1>(A, lds, offc, C);
+        tail_prolong_add(L, C);                                                 // main.cpp:337-341
+        for (int it = 0; it < A.Nup; it++) tail_sweep(L, A.omega, A.nomega);    // main.cpp:343
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_tail(const TailArgs A)
+{
+    extern __shared__ __align__(16) double lds[];
+    const int tid = threadIdx.x;
+    int total = 0;
 #pragma unroll
-    for (int l = TAIL_MAX_LEVELS - 2; l >= 0; l--) {  // main.cpp:335-346
-        if (l < A.nlev - 1) {
-            tail_prolong_add(L[l], L[l + 1], tid, nt);
-            for (int it = 0; it < A.Nup; it++) tail_sweep(L[l], omega, nomega, tid, nt);
-        }
-    }
+    for (int l = 0; l < TAIL_MAX_LEVELS; l++)
+        if (l < A.nlev) total += 3 * A.m[l] * A.m[l];
+    for (int k = tid; k < total; k += 1024) lds[k] = 0.0;  // main.cpp:295-299
+    __syncthreads();
+    LevelView L0 = tail_view<0>(A, lds, 0);
     {
-        const int m0 = A.m[0], mi = m0 - 2;
-        const double *__restrict__ u = L[0].v[L[0].cur];
-        for (int k = tid; k < mi * mi; k += nt) {
-            const int j = 1 + k / mi, i = 1 + k - (j - 1) * mi;
-            A.v[(size_t)i + (size_t)j * (size_t)A.ld] = u[i + j * m0];
-        }
+        const int m0 = A.m[0];
+        for (int j = tid >> 6; j < m0; j += 16)
+            for (int i = tid & 63; i < m0; i += 64) L0.f[i + j * m0] = A.f[(size_t)i + (size_t)j * (size_t)A.ld];
+    }
+    __syncthreads();
+    tail_level<0>(A, lds, 0, L0);
+    {
+        const int m0 = A.m[0];
+        const double *__restrict__ u = L0.u;
+        MGX_TAIL_FOR_INTERIOR(m0, i, j) A.v[(size_t)i + (size_t)j * (size_t)A.ld] = u[i + j * m0];
     }
 }
 
