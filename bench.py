@@ -50,6 +50,24 @@ def algorithmic_bytes_per_point(kernel, nd, nu):
     }[kernel]
 
 
+# What one fused launch must move at the very least (every array touched once): the
+# figure its real efficiency is judged by.  The table above prices the same work as the
+# separate passes of the reference, so a fused launch exceeds "100 %" of it.
+def fused_bytes_per_point(kernel, nd, nu):
+    return {
+        "k_stream:down": 8.0 + 8.0 + (8.0 if nd > 0 else 0.0) + 2.0,  # read u, f; write u'; write 1/4 coarse f
+        "k_stream:up": 2.0 + 8.0 + 8.0 + 8.0,                         # read 1/4 coarse v, u, f; write u'
+        "k_stream:norm": 16.0,
+        "k_stream:updown": 2.0 + 8.0 + 8.0 + 8.0 + 2.0,
+    }.get(kernel)
+
+
+# HBM bytes per launch from the PMC counters (rocprofv3 --pmc, separate passes, gfx950
+# corrections applied) for the default workload; measured in its own run, kept with the
+# round's profiles.  None for any other configuration.
+PMC_TRAFFIC = {("k_stream:updown", 16385, 2, 2): (8.34e9, "profiles/r01_lean_pmc_traffic.txt")}
+
+
 def rocprof_kernel_name(kernel, nd, nu):
     """The name the fine-level launch carries in a rocprofv3 kernel trace
     (template arguments NS, PA, NM, RES, ZERO_IN, STORE of k_stream)."""
@@ -75,26 +93,32 @@ def cycle_bytes(M, depth, nd, nu):
     return tot + 16.0 * M * M
 
 
-def cpu_baseline(M, nd, nu, omega, budget_note):
-    """Time the CPU oracle on one V-cycle of the same workload (1 thread)."""
+def cpu_baseline(M, nd, nu, omega, omp=False):
+    """Time the CPU oracle on V-cycles of the same workload: the plain restatement on one
+    thread (the reference is single-threaded), or its OpenMP build on the host cores this
+    process may use."""
     import numpy as np
     from oracle import oracle as O
     from multigrid_amd import rhs
-    O.lib()
+    L = O.lib_omp() if omp else O.lib()
+    cores = L.mgo_threads()
     f = rhs.random_np(M)
     v = np.zeros((M, M), order="F")
+    ncyc = 4 if omp else 1
+    if omp:
+        O.multigrid(f, v, 1.0 / (M - 1), 1, nd, nu, omega, 2, omp=True)  # first touch of the pages
     t0 = time.perf_counter()
-    O.multigrid(f, v, 1.0 / (M - 1), 1, nd, nu, omega, 2)
+    O.multigrid(f, v, 1.0 / (M - 1), ncyc, nd, nu, omega, 2, omp=omp)
     dt = time.perf_counter() - t0
-    return {"value": M * M / dt, "unit": "DOF/s", "cores": 1, "kind": "port",
-            "sample": "1 V(%d,%d) cycle at %dx%d incl. the two residual-norm passes, %.1f s%s"
-                      % (nd, nu, M, M, dt, budget_note)}
+    return {"value": M * M * ncyc / dt, "unit": "DOF/s", "cores": cores, "kind": "port",
+            "sample": "%d V(%d,%d) cycle(s) at %dx%d incl. the residual-norm passes, %.1f s"
+                      % (ncyc, nd, nu, M, M, dt)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100, help="V-cycles timed (the reference's default Nv is 100)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=16385, help="grid points per side (2^k+1)")
     ap.add_argument("--nd", type=int, default=2)
@@ -102,7 +126,8 @@ def main():
     ap.add_argument("--omega", type=float, default=0.6)
     ap.add_argument("--schedule", type=int, default=0, help="0 default, 1 stepwise, 2 fused")
     ap.add_argument("--slab", action="store_true", help="run the j-slab driver even on one GPU")
-    ap.add_argument("--tail-m", type=int, default=2049, help="slab driver: first replicated (tail) level size")
+    ap.add_argument("--tail-m", type=int, default=0,
+                    help="slab driver: largest replicated (tail) level size; 0 = 2049 on one rank, 1025 on more")
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
     ap.add_argument("--cpu-size", type=int, default=0, help="grid size for the CPU baseline (0 = --size)")
     args = ap.parse_args()
@@ -123,7 +148,8 @@ def main():
     ndev = torch.cuda.device_count()
     dev = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev)
-    if world > 1:
+    grouped = world > 1 or (os.environ.get("MGX_COMM_FORCE") == "1" and "MASTER_ADDR" in os.environ)
+    if grouped:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
@@ -147,11 +173,12 @@ def main():
         solver = slab.SlabSolver(M, dx, 2, schedule=args.schedule, tail_m=args.tail_m)
         solver.set_random_rhs()
         depth = solver.depth
-        schedule_name = "j-slabs x%d" % world
+        schedule_name = "j-slabs x%d, %d distributed levels, replicated tail from %d^2" % (
+            world, solver.ndist, solver.dims[solver.ndist])
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +190,7 @@ def main():
     out = solver.cycles(K, args.nd, args.nu, args.omega)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -186,8 +213,14 @@ def main():
                 pts = solver.profile_points()[kname] / cnt
             bpp = algorithmic_bytes_per_point(kname, args.nd, args.nu)
             achieved = bpp * pts / avg_s / 1e9
+            traffic, traffic_src = PMC_TRAFFIC.get((kname, M, args.nd, args.nu), (None, None)) if world == 1 else (None, None)
+            fbpp = fused_bytes_per_point(kname, args.nd, args.nu)
             roof = {"bound": "hbm", "kernel": rocprof_kernel_name(kname, args.nd, args.nu), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_GBps": traffic / avg_s / 1e9 if traffic else None,
+                    "fused_launch_min_bytes_per_point": fbpp,
+                    "fused_launch_min_GBps": fbpp * pts / avg_s / 1e9 if fbpp else None,
+                    "fused_launch_min_frac": fbpp * pts / avg_s / 1e9 / HBM_PEAK_GBS if fbpp else None,
                     "launches": cnt, "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_point": bpp,
                     "points_per_launch": pts,
                     "share_of_timed_region": tot_ms * 1e-3 / elapsed,
@@ -208,13 +241,14 @@ def main():
         }
         if world == 1 and args.cpu_baseline == "auto":
             try:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega, "")
+                line["cpu_baseline"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega)
+                line["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega, omp=True)
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "DOF/s", "cores": 1, "kind": "port",
                                         "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

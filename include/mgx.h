@@ -100,7 +100,10 @@ size_t mgx_plan_bytes(const mgx_plan *plan); /* HBM held by the plan */
 /* Fine-level device buffers (m*m doubles each) the caller may fill directly,
  * e.g. from a kernel of its own.  After writing v through this pointer call
  * mgx_plan_commit() so the plan refreshes its second (ping-pong) copy of the
- * boundary values. */
+ * boundary values.  mgx_plan_v_dev() names the buffer that holds the current
+ * iterate: the two ping-pong buffers may trade places inside mgx_plan_cycles()
+ * (no copy of the grid), so ask again after it returns.  mgx_plan_f_dev() never
+ * changes, and mgx_plan_vcycle_async() leaves mgx_plan_v_dev() as it is. */
 double *mgx_plan_f_dev(mgx_plan *plan);
 double *mgx_plan_v_dev(mgx_plan *plan);
 int mgx_plan_commit(mgx_plan *plan);

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <new>
+#include <utility>
 #include <vector>
 
 using namespace mgx;
@@ -679,8 +680,8 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
             LAUNCH(p, 0, MGX_KERNEL_RESNORM, launch_residual_norm(L0.v[L0.cur], L0.f, L0.m, 1, L0.m - 1, c0, slot, s));
         HIP_TRY(hipEventRecord(p->events[iter + 1], s));
     }
-    if (L0.cur != 0) {  // leave the solution in the buffer mgx_plan_v_dev() exposes
-        HIP_TRY(hipMemcpyAsync(L0.v[0], L0.v[1], sizeof(double) * L0.n(), hipMemcpyDeviceToDevice, s));
+    if (L0.cur != 0) {  // the buffer that holds the solution becomes the one mgx_plan_v_dev() names
+        std::swap(L0.v[0], L0.v[1]);
         L0.cur = 0;
     }
     HIP_TRY(hipStreamSynchronize(s));

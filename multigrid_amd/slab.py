@@ -169,6 +169,9 @@ class _Comm:
         self.rank = dist.get_rank(group) if self.on else 0
         self.size = dist.get_world_size(group) if self.on else 1
         self.backend = dist.get_backend(group) if self.on else "none"
+        # MGX_COMM_FORCE=1 issues the collectives even in a group of one rank (a way to
+        # exercise the RCCL calls on a box with a single GPU)
+        self.solo = self.size == 1 and not (self.on and os.environ.get("MGX_COMM_FORCE", "0") == "1")
         self.nexchanges = 0
         self.ngathers = 0
 
@@ -208,6 +211,8 @@ class _Comm:
                     if buf is not view:
                         copies.append((view, buf))
                     ops.append((dist.irecv, buf, peer, tag))
+        if not ops:
+            return None
         if self.backend == "nccl":
             reqs = dist.batch_isend_irecv([dist.P2POp(fn, buf, self._global(peer), self.group) for (fn, buf, peer, _)
                                            in ops])
@@ -228,7 +233,7 @@ class _Comm:
     def allgather(self, t, out=None):
         """Concatenation over ranks of equally shaped tensors along dim 0 (into `out` if given)."""
         self.ngathers += 1
-        if self.size == 1:
+        if self.solo:
             if out is not None:
                 out.copy_(t)
                 return out
@@ -237,7 +242,10 @@ class _Comm:
         staged = out is None or out.device != src.device
         buf = torch.empty((self.size * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype,
                           device=src.device) if staged else out
-        dist.all_gather(list(buf.chunk(self.size, 0)), src, group=self.group)
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(buf, src, group=self.group)
+        else:
+            dist.all_gather(list(buf.chunk(self.size, 0)), src, group=self.group)
         if out is None:
             return buf.to(t.device) if buf.device != t.device else buf
         if staged:
@@ -245,7 +253,7 @@ class _Comm:
         return out
 
     def allreduce_max_(self, t):
-        if self.size == 1:
+        if self.solo:
             return t
         buf = self._stage(t)
         dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.group)
@@ -305,10 +313,14 @@ class SlabSolver:
 
     W0 = 8  # halo columns of the level-0 arrays (the level-0 launch reads Ndown+Nup+2 <= 6)
 
-    def __init__(self, M, dx, coarsest=2, schedule=_lib.SCHEDULE_DEFAULT, backend=None, group=None, tail_m=2049,
+    def __init__(self, M, dx, coarsest=2, schedule=_lib.SCHEDULE_DEFAULT, backend=None, group=None, tail_m=None,
                  halo=8):
         self.be = backend if backend is not None else HipBackend(schedule)
         self.comm = _Comm(group)
+        if not tail_m:
+            # Every rank repeats the tail, so its cost does not shrink with the number of
+            # ranks while a distributed level's does: the more ranks, the smaller the tail.
+            tail_m = int(os.environ.get("MGX_TAIL_M", "0")) or (2049 if self.comm.size == 1 else 1025)
         self.M, self.dx, self.coarsest = M, dx, coarsest
         if M < 3 or M % 2 == 0:
             raise ValueError("Error: Input has even rows and columns!")  # main.cpp:415
@@ -387,7 +399,7 @@ class SlabSolver:
             for j in range(tb[k], tb[k + 1]):
                 rows[j] = k * pad + (j - self.tail_start[k])
         self.tail_rows = self.be.index_array(rows)
-        self.tail_gathered = self.be.zeros(R * pad, mt) if R > 1 else None
+        self.tail_gathered = self.be.zeros(R * pad, mt) if not self.comm.solo else None
         self._prof = False
         # post the level-0 halo exchange between the edge columns and the interior columns
         self.overlap = os.environ.get("MGX_SLAB_OVERLAP", "1") != "0"
@@ -576,8 +588,8 @@ class SlabSolver:
 
     def _tail(self, Ndown, Nup, omega):
         """All-gather the tail's right-hand side and run the tail on every rank."""
-        R, g = self.comm.size, self.comm.rank
-        if R > 1:
+        g = self.comm.rank
+        if not self.comm.solo:
             s = self.tail_start[g]
             mine = self.tail_f[s:s + self.tail_pad]
             self.comm.allgather(self.be.comm_tensor(mine), out=self.be.comm_tensor(self.tail_gathered))

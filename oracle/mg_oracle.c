@@ -20,6 +20,13 @@
  * pinned by the known answers captured from the reference when it was surveyed
  * (tests/golden/reference_known_answers.json) and, for Maximum/Minimum/+=, by
  * the reference's own DTSource sources compiled into oracle/_ref.
+ *
+ * The same file builds a second library, libmg_oracle_omp.so (-fopenmp): the
+ * loops over columns carry OpenMP pragmas.  Every grid point is computed by
+ * the same expression from the same inputs whatever thread runs it (Jacobi
+ * reads only the previous sweep), so the threaded build returns the same bits;
+ * it exists to time the algorithm on all host cores, the reference itself is
+ * single-threaded.
  */
 #include <math.h>
 #include <stdio.h>
@@ -29,26 +36,98 @@
 
 #define IDX(i, j, m) ((size_t)(i) + (size_t)(j) * (size_t)(m))
 
+#ifdef _OPENMP
+#include <omp.h>
+int mgo_threads(void) { return omp_get_max_threads(); }
+#else
+int mgo_threads(void) { return 1; }
+#endif
+
+/* memcpy / memset of a whole grid, split over the threads of the OpenMP build */
+static void grid_copy(double *dst, const double *src, size_t len)
+{
+    const size_t blk = (size_t)1 << 16;
+    const long nblk = (long)((len + blk - 1) / blk);
+#pragma omp parallel for schedule(static)
+    for (long b = 0; b < nblk; b++) {
+        size_t k0 = (size_t)b * blk, n = len - k0 < blk ? len - k0 : blk;
+        memcpy(dst + k0, src + k0, n * sizeof(double));
+    }
+}
+
+static void grid_zero(double *dst, size_t len)
+{
+    const size_t blk = (size_t)1 << 16;
+    const long nblk = (long)((len + blk - 1) / blk);
+#pragma omp parallel for schedule(static)
+    for (long b = 0; b < nblk; b++) {
+        size_t k0 = (size_t)b * blk, n = len - k0 < blk ? len - k0 : blk;
+        memset(dst + k0, 0, n * sizeof(double));
+    }
+}
+
 /* DTSource/DTDoubleArray.cpp:883-899 (Maximum) and :923-939 (Minimum):
  * start at -inf / +inf, `maxV < v ? v : maxV`, so NaNs never win.
  * main.cpp:147-150: calcNorm = max(Maximum(r), -Minimum(r)). */
 double mgo_maximum(const double *a, size_t len)
 {
     double maxv = -INFINITY;
+#ifdef _OPENMP
+    /* per-thread partial maxima over contiguous blocks, merged in block order with the
+     * same comparison: the value is that of the flat loop (max is exact and associative) */
+    enum { MAXT = 1024 };
+    double part[MAXT];
+    int nt = omp_get_max_threads();
+    if (nt > MAXT) nt = MAXT;
+    for (int t = 0; t < nt; t++) part[t] = -INFINITY;
+#pragma omp parallel num_threads(nt)
+    {
+        int t = omp_get_thread_num(), n = omp_get_num_threads();
+        size_t k0 = len * (size_t)t / (size_t)n, k1 = len * (size_t)(t + 1) / (size_t)n;
+        double mv = -INFINITY;
+        for (size_t k = k0; k < k1; k++) {
+            double v = a[k];
+            mv = (mv < v ? v : mv);
+        }
+        part[t] = mv;
+    }
+    for (int t = 0; t < nt; t++) maxv = (maxv < part[t] ? part[t] : maxv);
+#else
     for (size_t k = 0; k < len; k++) {
         double v = a[k];
         maxv = (maxv < v ? v : maxv);
     }
+#endif
     return maxv;
 }
 
 double mgo_minimum(const double *a, size_t len)
 {
     double minv = INFINITY;
+#ifdef _OPENMP
+    enum { MAXT = 1024 };
+    double part[MAXT];
+    int nt = omp_get_max_threads();
+    if (nt > MAXT) nt = MAXT;
+    for (int t = 0; t < nt; t++) part[t] = INFINITY;
+#pragma omp parallel num_threads(nt)
+    {
+        int t = omp_get_thread_num(), n = omp_get_num_threads();
+        size_t k0 = len * (size_t)t / (size_t)n, k1 = len * (size_t)(t + 1) / (size_t)n;
+        double mv = INFINITY;
+        for (size_t k = k0; k < k1; k++) {
+            double v = a[k];
+            mv = (mv > v ? v : mv);
+        }
+        part[t] = mv;
+    }
+    for (int t = 0; t < nt; t++) minv = (minv > part[t] ? part[t] : minv);
+#else
     for (size_t k = 0; k < len; k++) {
         double v = a[k];
         minv = (minv > v ? v : minv);
     }
+#endif
     return minv;
 }
 
@@ -70,7 +149,8 @@ void mgo_relax(double *u, const double *f, int m, double dx, int niter, double o
     size_t len = (size_t)m * (size_t)m;
     double *old = (double *)malloc(len * sizeof(double));
     for (int it = 0; it < niter; it++) {
-        memcpy(old, u, len * sizeof(double));
+        grid_copy(old, u, len);
+#pragma omp parallel for schedule(static)
         for (int j = 1; j < m - 1; j++) {
             for (int i = 1; i < m - 1; i++) {
                 double s = old[IDX(i - 1, j, m)] + old[IDX(i + 1, j, m)];
@@ -94,7 +174,8 @@ void mgo_residual(const double *u, const double *f, double *r, int m, double dx)
 {
     double h2 = dx * dx;
     double invh2 = 1.0 / h2;
-    memset(r, 0, (size_t)m * (size_t)m * sizeof(double));
+    grid_zero(r, (size_t)m * (size_t)m);
+#pragma omp parallel for schedule(static)
     for (int j = 1; j < m - 1; j++) {
         for (int i = 1; i < m - 1; i++) {
             double s = u[IDX(i - 1, j, m)] + u[IDX(i + 1, j, m)];
@@ -116,7 +197,8 @@ void mgo_coarsen(const double *fine, int mf, double *coarse, int mc)
     double selfw = 1.0 / 4.0;
     double neighborw = 1.0 / 8.0;
     double cornerw = 1.0 / 16.0;
-    memset(coarse, 0, (size_t)mc * (size_t)mc * sizeof(double));
+    grid_zero(coarse, (size_t)mc * (size_t)mc);
+#pragma omp parallel for schedule(static)
     for (int i = 1; i < mc - 1; i++) {
         for (int j = 1; j < mc - 1; j++) {
             double a = fine[IDX(i * 2, j * 2, mf)] * selfw;
@@ -136,7 +218,8 @@ void mgo_coarsen(const double *fine, int mf, double *coarse, int mc)
 /* main.cpp:223-253 refine(): bilinear interpolation into a zeroed array. */
 void mgo_refine(const double *coarse, int mc, double *fine, int mf)
 {
-    memset(fine, 0, (size_t)mf * (size_t)mf * sizeof(double));
+    grid_zero(fine, (size_t)mf * (size_t)mf);
+#pragma omp parallel for schedule(static)
     for (int j = 1; j < mf - 1; j++) {
         for (int i = 1; i < mf - 1; i++) {
             int I = i / 2, J = j / 2;
@@ -162,7 +245,8 @@ void mgo_refine(const double *coarse, int mc, double *fine, int mf)
  * over every entry, used at main.cpp:341. */
 void mgo_plus_equals(double *a, const double *b, size_t len)
 {
-    for (size_t k = 0; k < len; k++) a[k] = a[k] + b[k];
+#pragma omp parallel for schedule(static)
+    for (long k = 0; k < (long)len; k++) a[k] = a[k] + b[k];
 }
 
 /* main.cpp:153-169 direct_solve(): closed form for the single unknown of a
@@ -259,7 +343,7 @@ int mgo_multigrid(const double *f, double *v, int m, double dx, int Nv, int Ndow
                 double t0 = now_s();
                 mgo_relax(V[d], F[d], dims[d], hs[d], Nup, omega);
                 t_single += now_s() - t0;
-                memset(V[d + 1], 0, (size_t)dims[d + 1] * (size_t)dims[d + 1] * sizeof(double)); /* :345 */
+                grid_zero(V[d + 1], (size_t)dims[d + 1] * (size_t)dims[d + 1]); /* :345 */
             }
         } else {
             mgo_relax(V[0], F[0], m, dx, 1, omega); /* :348 */

@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_OMP = None
 _REF = None
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -29,38 +30,52 @@ def _f64(a):
     return a
 
 
+def lib_omp():
+    """The OpenMP build of the same restatement (same bits, all host cores)."""
+    global _OMP
+    if _OMP is None:
+        _OMP = _load("libmg_oracle_omp.so")
+    return _OMP
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libmg_oracle.so")
-        if not os.path.exists(path):
-            raise RuntimeError("oracle not built: run `make -C oracle`")
-        L = ctypes.CDLL(path)
-        L.mgo_maximum.restype = ctypes.c_double
-        L.mgo_maximum.argtypes = [_dp, ctypes.c_size_t]
-        L.mgo_minimum.restype = ctypes.c_double
-        L.mgo_minimum.argtypes = [_dp, ctypes.c_size_t]
-        L.mgo_calc_norm.restype = ctypes.c_double
-        L.mgo_calc_norm.argtypes = [_dp, ctypes.c_size_t]
-        L.mgo_relax.restype = None
-        L.mgo_relax.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double]
-        L.mgo_residual.restype = None
-        L.mgo_residual.argtypes = [_dp, _dp, _dp, ctypes.c_int, ctypes.c_double]
-        L.mgo_coarsen.restype = None
-        L.mgo_coarsen.argtypes = [_dp, ctypes.c_int, _dp, ctypes.c_int]
-        L.mgo_refine.restype = None
-        L.mgo_refine.argtypes = [_dp, ctypes.c_int, _dp, ctypes.c_int]
-        L.mgo_plus_equals.restype = None
-        L.mgo_plus_equals.argtypes = [_dp, _dp, ctypes.c_size_t]
-        L.mgo_direct_solve.restype = ctypes.c_int
-        L.mgo_direct_solve.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int]
-        L.mgo_depth.restype = ctypes.c_int
-        L.mgo_depth.argtypes = [ctypes.c_int, ctypes.c_int]
-        L.mgo_multigrid.restype = ctypes.c_int
-        L.mgo_multigrid.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
-                                    ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, _dp, _dp]
-        _LIB = L
+        _LIB = _load("libmg_oracle.so")
     return _LIB
+
+
+def _load(name):
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        raise RuntimeError("oracle not built: run `make -C oracle`")
+    L = ctypes.CDLL(path)
+    L.mgo_threads.restype = ctypes.c_int
+    L.mgo_threads.argtypes = []
+    L.mgo_maximum.restype = ctypes.c_double
+    L.mgo_maximum.argtypes = [_dp, ctypes.c_size_t]
+    L.mgo_minimum.restype = ctypes.c_double
+    L.mgo_minimum.argtypes = [_dp, ctypes.c_size_t]
+    L.mgo_calc_norm.restype = ctypes.c_double
+    L.mgo_calc_norm.argtypes = [_dp, ctypes.c_size_t]
+    L.mgo_relax.restype = None
+    L.mgo_relax.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double]
+    L.mgo_residual.restype = None
+    L.mgo_residual.argtypes = [_dp, _dp, _dp, ctypes.c_int, ctypes.c_double]
+    L.mgo_coarsen.restype = None
+    L.mgo_coarsen.argtypes = [_dp, ctypes.c_int, _dp, ctypes.c_int]
+    L.mgo_refine.restype = None
+    L.mgo_refine.argtypes = [_dp, ctypes.c_int, _dp, ctypes.c_int]
+    L.mgo_plus_equals.restype = None
+    L.mgo_plus_equals.argtypes = [_dp, _dp, ctypes.c_size_t]
+    L.mgo_direct_solve.restype = ctypes.c_int
+    L.mgo_direct_solve.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+    L.mgo_depth.restype = ctypes.c_int
+    L.mgo_depth.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.mgo_multigrid.restype = ctypes.c_int
+    L.mgo_multigrid.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, _dp, _dp]
+    return L
 
 
 def ref_lib():
@@ -134,13 +149,13 @@ def depth(m, coarsest):
     return lib().mgo_depth(m, coarsest)
 
 
-def multigrid(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pure_jacobi=False):
-    """Returns (Sol, ResNorms, Times) like main.cpp:445-455."""
+def multigrid(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pure_jacobi=False, omp=False):
+    """Returns (Sol, ResNorms, Times) like main.cpp:445-455.  omp=True runs the threaded build."""
     f = _f64(f)
     v = _f64(v).copy(order="F")
     res = np.zeros(Nv + 1)
     tim = np.zeros(Nv + 1)
-    rc = lib().mgo_multigrid(_ptr(f), _ptr(v), f.shape[0], dx, Nv, Ndown, Nup, omega, coarsest,
+    rc = (lib_omp() if omp else lib()).mgo_multigrid(_ptr(f), _ptr(v), f.shape[0], dx, Nv, Ndown, Nup, omega, coarsest,
                              int(bool(pure_jacobi)), _ptr(res), _ptr(tim))
     if rc != 0:
         raise ValueError("oracle refused the hierarchy (rc=%d)" % rc)

@@ -1,7 +1,7 @@
 """One rank of a multi-process SlabSolver test (launched by test_slab_cpu.py and
 test_gpu_slab.py with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set).
 
-  python slab_worker.py <backend: numpy|hip> <M> <Nv> <Ndown> <Nup> <omega> <tail_m> <pure_jacobi>
+  python slab_worker.py <backend: numpy|hip|hip-rccl> <M> <Nv> <Ndown> <Nup> <omega> <tail_m> <pure_jacobi>
 
 Every rank builds the same global problem, solves it with the slab driver over
 gloo and compares the gathered solution and the residual history with the CPU
@@ -24,15 +24,26 @@ def main():
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    rccl = backend == "hip-rccl"  # one GPU per rank over RCCL (a group of ONE rank on a one-GPU box)
+    grouped = world > 1 or rccl
+    if rccl:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dev = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=int(os.environ.get("RANK", "0")), world_size=world,
+                                device_id=torch.device("cuda", dev))
+    elif world > 1:
         dist.init_process_group("gloo")
-    rank = dist.get_rank() if world > 1 else 0
+    rank = dist.get_rank() if grouped else 0
 
     from oracle import oracle as O
     from multigrid_amd import rhs, slab
     if backend == "numpy":
         from slab_numpy_backend import NumpyBackend
         be = NumpyBackend(O)
+    elif rccl:
+        be = slab.HipBackend()
     else:
         torch.cuda.set_device(0)  # every rank shares the one GPU of the test box
         be = slab.HipBackend()
@@ -64,8 +75,8 @@ def main():
         if not same_sol:
             bad = np.argwhere(sol != ref_sol)
             print("first mismatches [i, j]:", bad[:5].tolist(), "of", len(bad), flush=True)
-    if world > 1:
-        flag = torch.tensor([0 if ok else 1])
+    if grouped:
+        flag = torch.tensor([0 if ok else 1], device="cuda" if rccl else "cpu")
         dist.all_reduce(flag)
         ok = int(flag.item()) == 0
         dist.destroy_process_group()

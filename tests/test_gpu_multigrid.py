@@ -176,3 +176,42 @@ def test_schedules_agree_at_16385(mg):
     rn = outs[0].ResidualNorms
     # (a random right-hand side lets the infinity norm rise in the first cycle)
     assert rn[1] > rn[2] > rn[3] and rn[3] < 0.5 * rn[0]
+
+
+# MGTester.m:22-35,144 sweeps omega, the sweep counts and the size on a random right-hand side
+@pytest.mark.parametrize("omega", [0.7, 0.8, 0.9])
+@pytest.mark.parametrize("nd,nu", [(1, 2), (2, 1), (3, 3), (5, 5), (7, 7)])
+def test_mgtester_parameter_sweep(mg, O, omega, nd, nu):
+    from multigrid_amd import rhs
+    for m in (129, 257, 513):
+        f = rhs.random_np(m)
+        dx = 1.0 / (m - 1)
+        v0 = np.zeros((m, m), order="F")
+        sol, rn, _ = O.multigrid(f, v0, dx, 4, nd, nu, omega, 2)
+        v = v0.copy(order="F")
+        out = mg.solve_host(f, v, dx, 4, nd, nu, omega, 2)
+        assert_bits(out.ResidualNorms, rn, "ResNorms m=%d" % m)
+        assert_bits(v, sol, "Sol m=%d" % m)
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+def test_plan_on_a_stream_of_the_callers(mg, O, sched):
+    """A plan created under a non-default stream launches everything there."""
+    import torch
+    from multigrid_amd import rhs
+    m = 513
+    dx = 1.0 / (m - 1)
+    f = rhs.random_np(m)
+    sol, rn, _ = O.multigrid(f, np.zeros((m, m), order="F"), dx, 4, 2, 2, 0.6, 2)
+    side = torch.cuda.Stream()
+    fd = mg.to_device(f)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan = mg.Plan(m, dx, 2, schedule=sched)
+        plan.set(fd, mg.colmajor(m, m))
+        out = plan.cycles(4, 2, 2, 0.6)
+        got = plan.get()
+    side.synchronize()
+    assert_bits(out.ResidualNorms, rn, "ResNorms")
+    assert_bits(mg.to_numpy(got), sol, "Sol")
+    plan.close()

@@ -46,6 +46,15 @@ def test_ranks_share_gpu_over_gloo(O, world, M, tail_m):
     assert "resnorms_equal=True sol_equal=True" in outs[0]
 
 
+def test_rccl_group_of_one_rank(O):
+    """The RCCL calls of the multi-GPU path (process group bound to the device, all-gather
+    into the tail plan's own buffer, max-reduction of the norm slots) on the one GPU there
+    is: a group of a single rank with the collectives forced on."""
+    codes, outs = run_ranks(1, ["hip-rccl", 1025, 3, 2, 2, 0.6, 129, 0], timeout=400, extra_env={"MGX_COMM_FORCE": "1"})
+    assert codes == [0], "\n".join(outs)
+    assert "resnorms_equal=True sol_equal=True" in outs[0]
+
+
 def test_slab_launch_rejects_missing_halo(mg):
     import ctypes
     from multigrid_amd import _lib

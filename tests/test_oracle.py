@@ -193,3 +193,19 @@ def test_ref_column_major(O):
     # DTDoubleArray.h:125-128: (i,j) -> i + j*m
     for (m, n, i, j) in [(5, 5, 1, 0), (5, 5, 0, 1), (9, 7, 3, 4), (3, 3, 2, 2)]:
         assert R.ref_offset_of(m, n, i, j) == i + j * m
+
+
+def test_threaded_oracle_build_returns_the_same_bits(O):
+    """libmg_oracle_omp.so (the all-cores CPU baseline) is the same source with OpenMP over
+    columns: Jacobi makes the result independent of the thread that computes a point."""
+    from multigrid_amd import rhs
+    M = 257
+    f = rhs.random_np(M)
+    rng = np.random.default_rng(3)
+    v0 = np.asfortranarray(rng.standard_normal((M, M)))
+    for (nd, nu, pj) in [(2, 2, False), (1, 3, False), (0, 0, True)]:
+        a = O.multigrid(f, v0, 1.0 / (M - 1), 3, nd, nu, 0.7, 2, pure_jacobi=pj)
+        b = O.multigrid(f, v0, 1.0 / (M - 1), 3, nd, nu, 0.7, 2, pure_jacobi=pj, omp=True)
+        assert_bits(a[0], b[0], "Sol")
+        assert_bits(a[1], b[1], "ResNorms")
+    assert O.lib_omp().mgo_threads() >= 1
