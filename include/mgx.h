@@ -30,7 +30,7 @@ extern "C" {
 
 #define MGX_OK 0
 #define MGX_ERR_ARG (-1)      /* bad size / null pointer / non-square / even size   */
-#define MGX_ERR_HIERARCHY (-2) /* depth < 0 or an even-sized coarse level           */
+#define MGX_ERR_HIERARCHY (-2) /* depth < 0 or an even-sized level above the coarsest  */
 #define MGX_ERR_HIP (-3)      /* a HIP runtime call failed                           */
 #define MGX_ERR_NOMEM (-4)
 #define MGX_ERR_STATE (-5)    /* plan used before data was set, etc.                 */
@@ -44,12 +44,27 @@ typedef struct mgx_options {
     int schedule;     /* 0 = default (fused), 1 = one kernel per reference operator (stepwise),
                          2 = fused streaming kernels                                            */
     int verbose;      /* 1 = print the reference's "Direct solver not defined" message etc.     */
-    int reserved[8];
+    int coarse_solve; /* MGX_COARSE_REFERENCE (0, default) or MGX_COARSE_EXACT, see below           */
+    int reserved[7];
 } mgx_options;
 
 #define MGX_SCHEDULE_DEFAULT 0
 #define MGX_SCHEDULE_STEPWISE 1
 #define MGX_SCHEDULE_FUSED 2
+
+/* What happens on the coarsest grid (main.cpp:331).
+ *   MGX_COARSE_REFERENCE  the reference's direct_solve (main.cpp:153-169): the closed form
+ *                         for a 3x3 grid, and NOTHING for any other size (the reference
+ *                         prints "Direct solver not defined" and carries on).
+ *   MGX_COARSE_EXACT      EXTENSION, no counterpart in the reference's MultiGrid(): a
+ *                         coarsest grid other than 3x3 (up to 65x65, odd or even) is solved
+ *                         exactly -- the 5-point system of the reference's unused
+ *                         getSparseSol() (main.cpp:79-120) -- by a sine-transform solver on
+ *                         the GPU.  Results agree with a Cholesky solve to rounding
+ *                         (about 1e-13 relative), not bit for bit.  A 3x3 grid still takes
+ *                         the closed form. */
+#define MGX_COARSE_REFERENCE 0
+#define MGX_COARSE_EXACT 1
 
 int mgx_version(void);
 const char *mgx_last_error(void);
@@ -174,6 +189,12 @@ int mgx_prolong_add(const double *coarse_dev, int mc, double *v_dev, int mf, voi
 /* direct_solve(gridtype&), main.cpp:153-169.  Returns 1 (not an error) and
  * leaves v unchanged when m != 3, as the reference does after printing. */
 int mgx_direct3x3(double *v_dev, const double *f_dev, int m, double dx, void *stream);
+
+/* EXTENSION (MGX_COARSE_EXACT as a single operator): the interior of the m x m grid v_dev
+ * (4 <= m <= 65) becomes the exact solution of 4 v(i,j) - (four neighbours) = -dx^2 f(i,j)
+ * for the boundary values v_dev holds: the system of getSparseSol(), main.cpp:79-110.
+ * Synchronous (builds and frees its tables). */
+int mgx_coarse_exact(double *v_dev, const double *f_dev, int m, double dx, void *stream);
 
 /* calcNorm(array), main.cpp:147-150 = max(Maximum, -Minimum) with
  * DTSource/DTDoubleArray.cpp:883-899,923-939 semantics (NaNs ignored).

@@ -27,7 +27,8 @@ class mgx_options(ctypes.Structure):
         ("stream", ctypes.c_void_p),
         ("schedule", ctypes.c_int),
         ("verbose", ctypes.c_int),
-        ("reserved", ctypes.c_int * 8),
+        ("coarse_solve", ctypes.c_int),
+        ("reserved", ctypes.c_int * 7),
     ]
 
 
@@ -52,6 +53,8 @@ SLAB_MAX_SWEEPS = 4
 SCHEDULE_DEFAULT = 0
 SCHEDULE_STEPWISE = 1
 SCHEDULE_FUSED = 2
+COARSE_REFERENCE = 0  # main.cpp:153-169: only a 3x3 coarsest grid is solved
+COARSE_EXACT = 1      # extension: any coarsest grid up to 65x65 is solved exactly
 
 # name -> (restype, argtypes); every symbol include/mgx.h declares.
 SIGNATURES = {
@@ -66,6 +69,7 @@ SIGNATURES = {
     "mgx_plan_depth": (ctypes.c_int, [_vp]),
     "mgx_plan_level_m": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mgx_plan_bytes": (ctypes.c_size_t, [_vp]),
+    "mgx_coarse_exact": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp]),
     "mgx_plan_f_dev": (_vp, [_vp]),
     "mgx_plan_v_dev": (_vp, [_vp]),
     "mgx_plan_commit": (ctypes.c_int, [_vp]),
@@ -125,11 +129,12 @@ def check(rc):
     return rc
 
 
-def make_options(device=-1, stream=None, schedule=SCHEDULE_DEFAULT, verbose=0):
+def make_options(device=-1, stream=None, schedule=SCHEDULE_DEFAULT, verbose=0, coarse_solve=0):
     o = mgx_options()
     o.struct_size = ctypes.sizeof(mgx_options)
     o.device = device
     o.stream = stream
     o.schedule = schedule
     o.verbose = verbose
+    o.coarse_solve = coarse_solve
     return o

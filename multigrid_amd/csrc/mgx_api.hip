@@ -3,6 +3,7 @@
 // reference's MultiGrid() (main.cpp:283-357).  Kernels live in
 // mgx_kernels.hip (one per reference operator) and mgx_stream.hip (fused).
 #include "../../include/mgx.h"
+#include "mgx_coarse.h"
 #include "mgx_internal.h"
 
 #include <math.h>
@@ -72,6 +73,8 @@ struct mgx_plan {
     int verbose = 0;
     int coarsest = 2;
     int depth = 0;
+    int coarse_solve = MGX_COARSE_REFERENCE;
+    double *exact_tables = nullptr;      // device tables of the exact coarsest-grid solve, or null
     int use_tail = 1;  // levels <= 65x65 of a cycle in one LDS-resident launch (MGX_NO_TAIL=1 disables)
     std::vector<Level> lv;
     double *r = nullptr;                 // residual scratch of the stepwise schedule (fine size)
@@ -167,6 +170,22 @@ int level_relax(mgx_plan *p, int d, int niter, double omega)
     return MGX_OK;
 }
 
+// main.cpp:331: the coarsest grid.  3x3: the reference's closed form; any other size:
+// nothing (the reference prints a message, main.cpp:167), or with MGX_COARSE_EXACT the
+// exact solve (an extension).
+int coarsest_solve(mgx_plan *p)
+{
+    Level &B = p->lv[p->depth];
+    if (B.m == 3) {
+        HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, p->stream));
+    } else if (p->exact_tables) {
+        HIP_TRY(launch_coarse_exact(B.v[B.cur], B.f, B.m, B.dx * B.dx, p->exact_tables, p->stream));
+    } else if (p->verbose) {
+        printf("Error: Direct solver not defined for %dx%d matrices!\n", B.m, B.m);
+    }
+    return MGX_OK;
+}
+
 // One V(Ndown,Nup) cycle, one kernel per reference operator:
 // the body of the loop at main.cpp:317-346.
 int vcycle_stepwise(mgx_plan *p, int Ndown, int Nup, double omega)
@@ -186,13 +205,9 @@ int vcycle_stepwise(mgx_plan *p, int Ndown, int Nup, double omega)
         // coarsen(): interior of the coarse f; its boundary stays 0 from allocation
         LAUNCH(p, d, MGX_KERNEL_RESTRICT, launch_restrict(p->r, L.m, C.f, C.m, 1, C.m - 1, 0, 0, s));
     }
-    {  // main.cpp:331
-        Level &B = p->lv[depth];
-        if (B.m == 3) {
-            HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, s));
-        } else if (p->verbose) {
-            printf("Error: Direct solver not defined for %dx%d matrices!\n", B.m, B.m);
-        }
+    {
+        int rc = coarsest_solve(p);
+        if (rc) return rc;
     }
     for (int d = depth - 1; d >= 0; d--) {  // main.cpp:335-346
         Level &L = p->lv[d];
@@ -360,6 +375,10 @@ int tail_first_level(const mgx_plan *p, const FusedCtx &cx)
         if (p->depth - d + 1 > TAIL_MAX_LEVELS) return -1;
         size_t n = 0;
         for (int k = d; k <= p->depth; k++) n += 3 * p->lv[k].n() * sizeof(double);
+        if (p->exact_tables) {
+            const size_t nc = (size_t)p->lv[p->depth].m - 2;
+            n += (nc * nc + nc) * sizeof(double);
+        }
         return n <= TAIL_MAX_LDS_BYTES ? d : -1;
     }
     return -1;
@@ -385,9 +404,10 @@ int fused_tail(mgx_plan *p, int T, const FusedCtx &cx)
     A.Nup = cx.Nup;
     A.omega = cx.omega;
     A.nomega = 1 - cx.omega;
+    A.exact_tables = p->exact_tables;
     L.cur = 0;
     HIP_TRY(launch_tail(A, p->stream));
-    if (p->verbose && p->lv[p->depth].m != 3)
+    if (p->verbose && p->lv[p->depth].m != 3 && !p->exact_tables)
         printf("Error: Direct solver not defined for %dx%d matrices!\n", p->lv[p->depth].m, p->lv[p->depth].m);
     return MGX_OK;
 }
@@ -406,12 +426,8 @@ int fused_coarse_legs(mgx_plan *p, const FusedCtx &cx)
         int rc = fused_tail(p, T, cx);
         if (rc) return rc;
     } else {
-        Level &B = p->lv[depth];
-        if (B.m == 3) {  // main.cpp:331
-            HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, p->stream));
-        } else if (p->verbose) {
-            printf("Error: Direct solver not defined for %dx%d matrices!\n", B.m, B.m);
-        }
+        int rc = coarsest_solve(p);
+        if (rc) return rc;
     }
     for (int d = last; d >= 1; d--) {
         int rc = fused_up(p, d, cx, nullptr, false);
@@ -425,11 +441,7 @@ int vcycle_fused(mgx_plan *p, int Ndown, int Nup, double omega, unsigned long lo
 {
     FusedCtx cx{Ndown, Nup, omega, zero0};
     if (zero0 && tail_first_level(p, cx) == 0) return fused_tail(p, 0, cx);  // the whole plan fits the tail
-    if (p->depth == 0) {
-        Level &B = p->lv[0];
-        if (B.m == 3) HIP_TRY(launch_direct3x3(B.v[B.cur], B.f, B.dx * B.dx, p->stream));
-        return MGX_OK;
-    }
+    if (p->depth == 0) return coarsest_solve(p);
     int rc = fused_down(p, 0, cx);
     if (!rc) rc = fused_coarse_legs(p, cx);
     if (!rc) rc = fused_up(p, 0, cx, (zero0 && cx.lean() && Ndown > 0) ? nullptr : norm_slot, false);
@@ -465,7 +477,9 @@ int mgx_plan_create(mgx_plan **out, int m, double dx, int coarsest, const mgx_op
     dims[0] = m;
     for (int d = 1; d <= depth; d++) {
         dims[d] = (dims[d - 1] - 1) / 2 + 1;  // main.cpp:293
-        if (dims[d] < 3 || (dims[d] % 2) == 0)
+        // refine() between level d and d+1 needs m_d = 2 m_{d+1} - 1, i.e. every level above
+        // the coarsest odd; the coarsest itself may be even
+        if (dims[d] < 3 || ((dims[d] % 2) == 0 && d < depth))
             return fail(MGX_ERR_HIERARCHY,
                         "mgx_plan_create: level %d would be %dx%d (needs odd >= 3): the reference indexes out of "
                         "range there", d, dims[d], dims[d]);
@@ -482,6 +496,7 @@ int mgx_plan_create(mgx_plan **out, int m, double dx, int coarsest, const mgx_op
         p->stream = (hipStream_t)opt->stream;
         p->verbose = opt->verbose;
         p->schedule = opt->schedule == MGX_SCHEDULE_DEFAULT ? MGX_SCHEDULE_FUSED : opt->schedule;
+        p->coarse_solve = opt->coarse_solve;
         if (opt->device >= 0) {
             hipError_t e = hipSetDevice(opt->device);
             if (e != hipSuccess) {
@@ -493,6 +508,16 @@ int mgx_plan_create(mgx_plan **out, int m, double dx, int coarsest, const mgx_op
     if (p->schedule != MGX_SCHEDULE_STEPWISE && p->schedule != MGX_SCHEDULE_FUSED) {
         delete p;
         return fail(MGX_ERR_ARG, "mgx_plan_create: schedule %d is not available", opt ? opt->schedule : -1);
+    }
+    if (p->coarse_solve != MGX_COARSE_REFERENCE && p->coarse_solve != MGX_COARSE_EXACT) {
+        delete p;
+        return fail(MGX_ERR_ARG, "mgx_plan_create: coarse_solve %d is not available", opt ? opt->coarse_solve : -1);
+    }
+    if (p->coarse_solve == MGX_COARSE_EXACT && dims[depth] != 3 && dims[depth] > COARSE_EXACT_MAX_M) {
+        delete p;
+        return fail(MGX_ERR_ARG, "mgx_plan_create: the exact coarsest-grid solve takes at most %dx%d points, the "
+                                 "coarsest level here has %dx%d (raise the depth with a smaller `coarsest`)",
+                    COARSE_EXACT_MAX_M, COARSE_EXACT_MAX_M, dims[depth], dims[depth]);
     }
     {
         hipError_t e = hipGetDevice(&p->device);
@@ -524,6 +549,17 @@ int mgx_plan_create(mgx_plan **out, int m, double dx, int coarsest, const mgx_op
     }
     rc = plan_alloc(p, (void **)&p->r, sizeof(double) * p->lv[0].n());
     if (rc) { mgx_plan_destroy(p); return rc; }
+    if (p->coarse_solve == MGX_COARSE_EXACT && dims[depth] != 3) {
+        const size_t n = (size_t)dims[depth] - 2;
+        std::vector<double> t(n * n + n);
+        coarse_tables(dims[depth], t.data());
+        rc = plan_alloc(p, (void **)&p->exact_tables, sizeof(double) * t.size());
+        if (rc) { mgx_plan_destroy(p); return rc; }
+        hipError_t e = hipMemcpyAsync(p->exact_tables, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice,
+                                      p->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->stream);  // t goes out of scope
+        if (e != hipSuccess) { mgx_plan_destroy(p); return fail(MGX_ERR_HIP, "table upload: %s", hipGetErrorString(e)); }
+    }
     *out = p;
     return MGX_OK;
 }
@@ -538,6 +574,7 @@ int mgx_plan_destroy(mgx_plan *p)
         if (L.v[1]) (void)hipFree(L.v[1]);
     }
     if (p->r) (void)hipFree(p->r);
+    if (p->exact_tables) (void)hipFree(p->exact_tables);
     if (p->slots) (void)hipFree(p->slots);
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->evpool) (void)hipEventDestroy(e);
@@ -646,7 +683,14 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
     const SweepCoef c0 = make_coef(L0.dx, omega);
     HIP_TRY(hipMemsetAsync(p->slots, 0, sizeof(unsigned long long) * (size_t)(Nv + 1), s));
     // main.cpp:307
-    LAUNCH(p, 0, MGX_KERNEL_RESNORM, launch_residual_norm(L0.v[L0.cur], L0.f, L0.m, 1, L0.m - 1, c0, p->slots + 0, s));
+    if (p->schedule == MGX_SCHEDULE_FUSED) {  // the streaming kernel's 16-byte loads: 0.79 vs 1.09 ms at 16385^2
+        StreamArgs A = level_args(L0, nullptr, omega);
+        A.slot = p->slots + 0;
+        rc = stream_chain(p, 0, MGX_KERNEL_RESNORM, s, 0, 0, 2, 0, A, L0.v, L0.cur);
+        if (rc) return rc;
+    } else {
+        LAUNCH(p, 0, MGX_KERNEL_RESNORM, launch_residual_norm(L0.v[L0.cur], L0.f, L0.m, 1, L0.m - 1, c0, p->slots + 0, s));
+    }
     HIP_TRY(hipEventRecord(p->events[0], s));
     for (int iter = 0; iter < Nv; iter++) {  // main.cpp:309
         unsigned long long *slot = p->slots + iter + 1;
@@ -798,6 +842,25 @@ int mgx_direct3x3(double *v, const double *f, int m, double dx, void *stream)
     if (!v || !f) return fail(MGX_ERR_ARG, "mgx_direct3x3: null pointer");
     if (m != 3) return 1;  // main.cpp:167: message, no change
     HIP_TRY(launch_direct3x3(v, f, dx * dx, (hipStream_t)stream));
+    return MGX_OK;
+}
+
+int mgx_coarse_exact(double *v, const double *f, int m, double dx, void *stream)
+{
+    if (!v || !f) return fail(MGX_ERR_ARG, "mgx_coarse_exact: null pointer");
+    if (m < 4 || m > COARSE_EXACT_MAX_M)
+        return fail(MGX_ERR_ARG, "mgx_coarse_exact: m=%d outside 4..%d", m, COARSE_EXACT_MAX_M);
+    const size_t n = (size_t)m - 2;
+    std::vector<double> t(n * n + n);
+    coarse_tables(m, t.data());
+    double *dt = nullptr;
+    HIP_TRY(hipMalloc((void **)&dt, sizeof(double) * t.size()));
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(dt, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = launch_coarse_exact(v, f, m, dx * dx, dt, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(dt);
+    if (e != hipSuccess) return fail(MGX_ERR_HIP, "mgx_coarse_exact: %s", hipGetErrorString(e));
     return MGX_OK;
 }
 

@@ -69,8 +69,12 @@ struct TailArgs {
     double h2[TAIL_MAX_LEVELS] = {0}, invh2[TAIL_MAX_LEVELS] = {0};
     int Ndown = 0, Nup = 0;
     double omega = 0, nomega = 0;
+    // extension: device tables of the exact coarsest-grid solve (mgx_coarse.h), or null for
+    // the reference's behaviour (a coarsest grid that is not 3x3 is left as it is)
+    const double *exact_tables = nullptr;
+    int tables_off = 0, tables_len = 0;  // filled by the launcher: position (doubles) in LDS
 };
-size_t tail_lds_bytes(const TailArgs &A);
+size_t tail_lds_bytes(const TailArgs &A);  // hierarchy + tables
 // One V(Ndown,Nup) cycle over the tail's levels from a zero iterate on its top level.
 hipError_t launch_tail(const TailArgs &A, hipStream_t s);
 

@@ -7,7 +7,8 @@
 // main.cpp:363-370): -v/--Nv (also the first positional argument, default
 // 100), -b/--Nbefore (3), -a/--Nafter (3), -o/--omega (0.6), -c/--coarsest (2),
 // -h/--help.  Added: --input / --output file names, --stepwise (one kernel per
-// reference operator instead of the fused schedule).
+// reference operator instead of the fused schedule), --exact-coarse (solve a
+// coarsest grid other than 3x3 exactly instead of leaving it as it is).
 #include "../../include/mgx.h"
 #include "mat4.h"
 
@@ -30,14 +31,15 @@ void usage()
            "  -c [ --coarsest ] arg (=2)    threshold dimension to use a direct solver\n"
            "  --input arg (=Input.mat)      MAT-v4 file holding f and f_loc\n"
            "  --output arg (=Output.mat)    MAT-v4 file receiving Sol, ResNorms, Times\n"
-           "  --stepwise                    one GPU kernel per reference operator\n\n");
+           "  --stepwise                    one GPU kernel per reference operator\n"
+           "  --exact-coarse                solve a coarsest grid other than 3x3 exactly\n\n");
 }
 
 struct Args {
     int Nv = 100, Ndown = 3, Nup = 3, coarsest = 2;
     double omega = 0.6;
     std::string input = "Input.mat", output = "Output.mat";
-    bool help = false, stepwise = false;
+    bool help = false, stepwise = false, exact_coarse = false;
 };
 
 bool parse_int(const char *s, int &out)
@@ -84,6 +86,7 @@ int parse(int argc, const char *argv[], Args &a)
         }
         if (key == "help") { a.help = true; continue; }
         if (key == "stepwise") { a.stepwise = true; continue; }
+        if (key == "exact-coarse") { a.exact_coarse = true; continue; }
         if (!has_val) {
             if (k + 1 >= argc) { fprintf(stderr, "the required argument for option '--%s' is missing\n", key.c_str()); return 2; }
             val = argv[++k];
@@ -163,6 +166,7 @@ int main(int argc, const char *argv[])
     opt.device = -1;
     opt.verbose = 1;  // the reference prints "Direct solver not defined ..." (main.cpp:167)
     opt.schedule = a.stepwise ? MGX_SCHEDULE_STEPWISE : MGX_SCHEDULE_DEFAULT;
+    opt.coarse_solve = a.exact_coarse ? MGX_COARSE_EXACT : MGX_COARSE_REFERENCE;
     rc = mgx_solve2d(f.data(), u.data(), M, N, dx, a.Nv, a.Ndown, a.Nup, a.omega, a.coarsest, 0, resnorm.data(),
                      times.data(), &opt);  // main.cpp:445
     if (rc != MGX_OK) {

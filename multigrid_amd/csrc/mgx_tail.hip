@@ -17,6 +17,7 @@
 // iterate, as every coarse level does when the down sweep reaches it
 // (main.cpp:295-299,345).  Expressions are those of mgx_kernels.hip, evaluated
 // in the same order: identical bits.
+#include "mgx_coarse.h"
 #include "mgx_internal.h"
 
 namespace mgx {
@@ -158,6 +159,12 @@ __device__ __forceinline__ void tail_level(const TailArgs &A, double *lds, int o
                 u[1 + 1 * 3] = s * 0.25;
             }
             __syncthreads();
+        } else if (A.exact_tables) {
+            // extension: exact solve of a coarsest grid that is not 3x3.  The level's idle
+            // iterate array and, once read, its right-hand side serve as scratch.
+            const int n = L.m - 2;
+            const double *S = lds + A.tables_off;
+            coarse_exact_solve(L.u, L.m, L.f, L.m, L.m, L.h2, S, S + n * n, L.w, L.f);
         }
         return;
     }
@@ -182,6 +189,8 @@ __global__ __launch_bounds__(1024) void k_tail(const TailArgs A)
     for (int l = 0; l < TAIL_MAX_LEVELS; l++)
         if (l < A.nlev) total += 3 * A.m[l] * A.m[l];
     for (int k = tid; k < total; k += 1024) lds[k] = 0.0;  // main.cpp:295-299
+    if (A.exact_tables)
+        for (int k = tid; k < A.tables_len; k += 1024) lds[A.tables_off + k] = A.exact_tables[k];
     __syncthreads();
     LevelView L0 = tail_view<0>(A, lds, 0);
     {
@@ -204,12 +213,21 @@ size_t tail_lds_bytes(const TailArgs &A)
 {
     size_t n = 0;
     for (int l = 0; l < A.nlev; l++) n += 3 * (size_t)A.m[l] * (size_t)A.m[l];
+    if (A.exact_tables && A.nlev >= 1) {
+        const size_t nc = (size_t)A.m[A.nlev - 1] - 2;
+        n += nc * nc + nc;
+    }
     return n * sizeof(double);
 }
 
-hipError_t launch_tail(const TailArgs &A, hipStream_t s)
+hipError_t launch_tail(const TailArgs &A0, hipStream_t s)
 {
+    TailArgs A = A0;
     if (A.nlev < 1 || A.nlev > TAIL_MAX_LEVELS) return hipErrorInvalidValue;
+    A.tables_off = 0;
+    for (int l = 0; l < A.nlev; l++) A.tables_off += 3 * A.m[l] * A.m[l];
+    const int nc = A.m[A.nlev - 1] - 2;
+    A.tables_len = A.exact_tables ? nc * nc + nc : 0;
     const size_t bytes = tail_lds_bytes(A);
     if (bytes > TAIL_MAX_LDS_BYTES) return hipErrorInvalidValue;
     // more than 64 KB of dynamic LDS must be requested once per device

@@ -57,12 +57,13 @@ class HipBackend:
     tensors of shape (ncols, m): row k of the tensor is column k of the slab."""
     name = "hip"
 
-    def __init__(self, schedule=_lib.SCHEDULE_DEFAULT):
+    def __init__(self, schedule=_lib.SCHEDULE_DEFAULT, coarse_solve=_lib.COARSE_REFERENCE):
         if not torch.cuda.is_available():
             raise RuntimeError("multigrid_amd.slab: HipBackend needs a GPU; there is no CPU path")
         self.L = _lib.load()
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.schedule = schedule
+        self.coarse_solve = coarse_solve  # what the replicated tail does on the coarsest grid
 
     def zeros(self, ncols, m):
         return torch.zeros((ncols, m), dtype=torch.float64, device=self.device)
@@ -141,7 +142,7 @@ class _HipTail:
         self.m = m
         self.h = ctypes.c_void_p()
         opt = _lib.make_options(device=torch.cuda.current_device(), stream=torch.cuda.current_stream().cuda_stream,
-                                schedule=be.schedule)
+                                schedule=be.schedule, coarse_solve=be.coarse_solve)
         _lib.check(be.L.mgx_plan_create(ctypes.byref(self.h), m, dx, coarsest, ctypes.byref(opt)))
         # the plan's own fine-level buffers as tensors (no copies in or out):
         # row k of the tensor is column k of the level
@@ -314,8 +315,8 @@ class SlabSolver:
     W0 = 8  # halo columns of the level-0 arrays (the level-0 launch reads Ndown+Nup+2 <= 6)
 
     def __init__(self, M, dx, coarsest=2, schedule=_lib.SCHEDULE_DEFAULT, backend=None, group=None, tail_m=None,
-                 halo=8):
-        self.be = backend if backend is not None else HipBackend(schedule)
+                 halo=8, coarse_solve=_lib.COARSE_REFERENCE):
+        self.be = backend if backend is not None else HipBackend(schedule, coarse_solve)
         self.comm = _Comm(group)
         if not tail_m:
             # Every rank repeats the tail, so its cost does not shrink with the number of
@@ -333,7 +334,7 @@ class SlabSolver:
         for _ in range(self.depth):
             dims.append((dims[-1] - 1) // 2 + 1)  # main.cpp:293
             hs.append(hs[-1] * 2.0)               # main.cpp:297
-            if dims[-1] < 3 or dims[-1] % 2 == 0:
+            if dims[-1] < 3 or (dims[-1] % 2 == 0 and len(dims) - 1 < self.depth):
                 raise ValueError("level of size %d: the reference indexes out of range there" % dims[-1])
         self.dims, self.hs = dims, hs
         R = self.comm.size

@@ -130,6 +130,16 @@ def prolong_add(coarse, v):
     _lib.check(L.mgx_prolong_add(coarse.data_ptr(), mc, v.data_ptr(), mf, _stream_ptr()))
 
 
+def coarse_exact(p):
+    """EXTENSION (no counterpart in the reference's MultiGrid): exact solve of the grid p
+    (4..65 points per side) for the boundary values p.v holds: the 5-point system of
+    getSparseSol(), main.cpp:79-110.  p.v is overwritten in place."""
+    _require_gpu()
+    m, _ = _check_colmajor(p.v, "p.v")
+    L = _lib.load()
+    _lib.check(L.mgx_coarse_exact(p.v.data_ptr(), p.f.data_ptr(), m, p.dx, _stream_ptr()))
+
+
 def direct_solve(p):
     """main.cpp:153-169.  Returns False (and changes nothing) unless the grid is 3x3."""
     _require_gpu()
@@ -198,14 +208,15 @@ def fused_up(coarse, p, Niter, omega, norm=False):
 class Plan:
     """Device-resident level hierarchy (mgx_plan_*), reusable across solves."""
 
-    def __init__(self, m, dx, coarsest=2, schedule=_lib.SCHEDULE_DEFAULT, verbose=0):
+    def __init__(self, m, dx, coarsest=2, schedule=_lib.SCHEDULE_DEFAULT, verbose=0,
+                 coarse_solve=_lib.COARSE_REFERENCE):
         _require_gpu()
         self._L = _lib.load()
         self._h = ctypes.c_void_p()
         self.m = m
         self.dx = dx
         opt = _lib.make_options(device=torch.cuda.current_device(), stream=torch.cuda.current_stream().cuda_stream,
-                                schedule=schedule, verbose=verbose)
+                                schedule=schedule, verbose=verbose, coarse_solve=coarse_solve)
         _lib.check(self._L.mgx_plan_create(ctypes.byref(self._h), m, dx, coarsest, ctypes.byref(opt)))
 
     def close(self):
@@ -271,7 +282,8 @@ class Plan:
         return MGOutputs(res, tim)
 
 
-def MultiGrid(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi=False, schedule=_lib.SCHEDULE_DEFAULT):
+def MultiGrid(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi=False, schedule=_lib.SCHEDULE_DEFAULT,
+              coarse_solve=_lib.COARSE_REFERENCE):
     """main.cpp:283-357: Nv V(Ndown,Nup) cycles; prob.v is overwritten in place.
 
     Returns MGOutputs(ResidualNorms[Nv+1], Times[Nv+1])."""
@@ -279,7 +291,7 @@ def MultiGrid(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi=False, schedule=
     m = _square_odd(prob.f, "prob.f")
     if _square_odd(prob.v, "prob.v") != m:
         raise ValueError("f and v differ in size")
-    plan = Plan(m, prob.dx, coarsest, schedule)
+    plan = Plan(m, prob.dx, coarsest, schedule, coarse_solve=coarse_solve)
     try:
         plan.set(prob.f, prob.v)
         out = plan.cycles(Nv, Ndown, Nup, omega, pureJacobi)
@@ -290,7 +302,8 @@ def MultiGrid(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi=False, schedule=
     return out
 
 
-def solve_host(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pureJacobi=False, schedule=_lib.SCHEDULE_DEFAULT):
+def solve_host(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pureJacobi=False, schedule=_lib.SCHEDULE_DEFAULT,
+               coarse_solve=_lib.COARSE_REFERENCE):
     """mgx_solve2d on host numpy arrays (the drop-in for main.cpp:445).
 
     f, v: Fortran-ordered float64 m x n; v is overwritten.  Returns MGOutputs."""
@@ -301,7 +314,7 @@ def solve_host(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pureJacobi=False, sc
     res = np.zeros(Nv + 1)
     tim = np.zeros(Nv + 1)
     L = _lib.load()
-    opt = _lib.make_options(schedule=schedule)
+    opt = _lib.make_options(schedule=schedule, coarse_solve=coarse_solve)
     _lib.check(L.mgx_solve2d(f.ctypes.data, v.ctypes.data, m, n, dx, Nv, Ndown, Nup, omega, coarsest,
                              int(bool(pureJacobi)), res.ctypes.data, tim.ctypes.data, ctypes.byref(opt)))
     return MGOutputs(res, tim)

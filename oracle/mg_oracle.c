@@ -268,6 +268,74 @@ int mgo_direct_solve(double *u, const double *f, int m, double dx, int quiet)
     return 1;
 }
 
+/* EXTENSION (not reference behaviour): exact solve of the coarsest grid, any size.
+ * The system is the one the reference's unused getSparseSol() assembles
+ * (main.cpp:79-110): 4 u(i,j) - sum of the four neighbours = -h^2 f(i,j), boundary
+ * values of u moved to the right-hand side; unknowns ordered i fastest.  Solved by
+ * a banded Cholesky factorisation (half bandwidth n = m-2), the textbook
+ * algorithm; pinned against Eigen::SimplicialCholesky, which the reference calls
+ * at main.cpp:119-120, through oracle/_ref/libeigenref.so.  Returns 0, or 1 if
+ * the matrix is not positive definite (cannot happen for this matrix). */
+int mgo_coarse_exact(double *u, const double *f, int m, double dx)
+{
+    const int n = m - 2;
+    if (n < 1) return 0;
+    const size_t N = (size_t)n * (size_t)n;
+    const size_t bw = (size_t)n + 1; /* L(r, c) for r-c = 0..n sits at band[r*bw + (r-c)] */
+    double *band = (double *)calloc(N * bw, sizeof(double));
+    double *x = (double *)malloc(N * sizeof(double));
+    const double h2 = dx * dx;
+    for (int j = 1; j <= n; j++) {
+        for (int i = 1; i <= n; i++) {
+            size_t row = (size_t)(i - 1) + (size_t)(j - 1) * (size_t)n;
+            double b = -h2 * f[IDX(i, j, m)];
+            band[row * bw + 0] = 4.0;
+            if (i > 1) band[row * bw + 1] = -1.0; else b += u[IDX(i - 1, j, m)];
+            if (i == n) b += u[IDX(i + 1, j, m)];
+            if (j > 1) band[row * bw + (size_t)n] += -1.0; else b += u[IDX(i, j - 1, m)];
+            if (j == n) b += u[IDX(i, j + 1, m)];
+            x[row] = b;
+        }
+    }
+    /* for n == 1 the two sub-diagonals coincide at distance 1 and neither exists */
+    int rc = 0;
+    for (size_t c = 0; c < N && !rc; c++) {
+        size_t k0 = c > (size_t)n ? c - (size_t)n : 0;
+        double d = band[c * bw + 0];
+        for (size_t k = k0; k < c; k++) d -= band[c * bw + (c - k)] * band[c * bw + (c - k)];
+        if (!(d > 0.0)) { rc = 1; break; }
+        d = sqrt(d);
+        band[c * bw + 0] = d;
+        size_t r1 = c + (size_t)n < N - 1 ? c + (size_t)n : N - 1;
+        for (size_t r = c + 1; r <= r1; r++) {
+            size_t kk0 = r > (size_t)n ? r - (size_t)n : 0;
+            if (kk0 < k0) kk0 = k0;
+            double t = band[r * bw + (r - c)];
+            for (size_t k = kk0; k < c; k++) t -= band[r * bw + (r - k)] * band[c * bw + (c - k)];
+            band[r * bw + (r - c)] = t / d;
+        }
+    }
+    if (!rc) {
+        for (size_t r = 0; r < N; r++) { /* L y = b */
+            size_t k0 = r > (size_t)n ? r - (size_t)n : 0;
+            double t = x[r];
+            for (size_t k = k0; k < r; k++) t -= band[r * bw + (r - k)] * x[k];
+            x[r] = t / band[r * bw + 0];
+        }
+        for (size_t rr = N; rr-- > 0;) { /* L^T x = y */
+            size_t r1 = rr + (size_t)n < N - 1 ? rr + (size_t)n : N - 1;
+            double t = x[rr];
+            for (size_t k = rr + 1; k <= r1; k++) t -= band[k * bw + (k - rr)] * x[k];
+            x[rr] = t / band[rr * bw + 0];
+        }
+        for (int j = 1; j <= n; j++)
+            for (int i = 1; i <= n; i++) u[IDX(i, j, m)] = x[(size_t)(i - 1) + (size_t)(j - 1) * (size_t)n];
+    }
+    free(band);
+    free(x);
+    return rc;
+}
+
 /* main.cpp:286: depth = int(log2(1.0f*(M-1)/coarsest) + 0.5f), float math. */
 int mgo_depth(int m, int coarsest)
 {
@@ -288,10 +356,23 @@ static double now_s(void)
  * f, v are the fine-level arrays (v in/out, boundary values already set).
  * The unused `before`/`lowest` residual passes (:311,:332) have no effect on
  * any output and are skipped.  Returns 0, or <0 for a hierarchy this
- * restatement refuses (depth<0 or an even-sized level, where the reference
- * indexes out of range). */
+ * restatement refuses (depth<0 or an even-sized level above the coarsest, where
+ * the reference indexes out of range in refine(); the coarsest level itself may be
+ * even).  coarse_exact != 0 is the EXTENSION: a coarsest grid that is not 3x3 is
+ * solved exactly (mgo_coarse_exact) instead of being left as it is (:167). */
+int mgo_multigrid_opt(const double *f, double *v, int m, double dx, int Nv, int Ndown, int Nup,
+                      double omega, int coarsest, int pure_jacobi, int coarse_exact, double *resnorm,
+                      double *times);
+
 int mgo_multigrid(const double *f, double *v, int m, double dx, int Nv, int Ndown, int Nup,
                   double omega, int coarsest, int pure_jacobi, double *resnorm, double *times)
+{
+    return mgo_multigrid_opt(f, v, m, dx, Nv, Ndown, Nup, omega, coarsest, pure_jacobi, 0, resnorm, times);
+}
+
+int mgo_multigrid_opt(const double *f, double *v, int m, double dx, int Nv, int Ndown, int Nup,
+                      double omega, int coarsest, int pure_jacobi, int coarse_exact, double *resnorm,
+                      double *times)
 {
     if (m < 3 || (m % 2) == 0 || coarsest < 1) return -1;
     int depth = mgo_depth(m, coarsest);
@@ -305,7 +386,7 @@ int mgo_multigrid(const double *f, double *v, int m, double dx, int Nv, int Ndow
         hs[d] = hs[d - 1] * 2.0;             /* :297 */
     }
     for (int d = 0; d <= depth; d++) {
-        if (dims[d] < 3 || (dims[d] % 2) == 0) {
+        if (dims[d] < 3 || ((dims[d] % 2) == 0 && d < depth)) {
             if (d > 0 || depth > 0) { free(dims); free(hs); return -3; }
         }
     }
@@ -335,7 +416,10 @@ int mgo_multigrid(const double *f, double *v, int m, double dx, int Nv, int Ndow
                 mgo_residual(V[d], F[d], res, dims[d], hs[d]);
                 mgo_coarsen(res, dims[d], F[d + 1], dims[d + 1]);
             }
-            mgo_direct_solve(V[depth], F[depth], dims[depth], hs[depth], 0); /* :331 */
+            if (coarse_exact && dims[depth] != 3)
+                mgo_coarse_exact(V[depth], F[depth], dims[depth], hs[depth]);
+            else
+                mgo_direct_solve(V[depth], F[depth], dims[depth], hs[depth], 0); /* :331 */
             for (int d = depth - 1; d >= 0; d--) { /* :335-346 */
                 size_t nd = (size_t)dims[d] * (size_t)dims[d];
                 mgo_refine(V[d + 1], dims[d + 1], refined, dims[d]);

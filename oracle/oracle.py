@@ -72,6 +72,11 @@ def _load(name):
     L.mgo_direct_solve.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int]
     L.mgo_depth.restype = ctypes.c_int
     L.mgo_depth.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.mgo_coarse_exact.restype = ctypes.c_int
+    L.mgo_coarse_exact.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double]
+    L.mgo_multigrid_opt.restype = ctypes.c_int
+    L.mgo_multigrid_opt.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp]
     L.mgo_multigrid.restype = ctypes.c_int
     L.mgo_multigrid.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, _dp, _dp]
@@ -149,14 +154,44 @@ def depth(m, coarsest):
     return lib().mgo_depth(m, coarsest)
 
 
-def multigrid(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pure_jacobi=False, omp=False):
-    """Returns (Sol, ResNorms, Times) like main.cpp:445-455.  omp=True runs the threaded build."""
+_EIG = None
+
+
+def ref_eigen():
+    """Eigen::SimplicialCholesky on the 5-point system (oracle/_ref), or None if not built."""
+    global _EIG
+    if _EIG is None:
+        path = os.path.join(_HERE, "_ref", "libeigenref.so")
+        if not os.path.exists(path):
+            return None
+        L = ctypes.CDLL(path)
+        L.ref_poisson_exact.restype = ctypes.c_int
+        L.ref_poisson_exact.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double]
+        _EIG = L
+    return _EIG
+
+
+def coarse_exact(u, f, dx, eigen=False):
+    """EXTENSION: exact solve of one grid (boundary of u kept); eigen=True uses the reference's Eigen."""
+    u = _f64(u).copy(order="F")
+    f = _f64(f)
+    fn = ref_eigen().ref_poisson_exact if eigen else lib().mgo_coarse_exact
+    rc = fn(_ptr(f), _ptr(u), u.shape[0], dx) if eigen else fn(_ptr(u), _ptr(f), u.shape[0], dx)
+    if rc != 0:
+        raise ValueError("exact solve failed (rc=%d)" % rc)
+    return u
+
+
+def multigrid(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pure_jacobi=False, omp=False, coarse_exact=False):
+    """Returns (Sol, ResNorms, Times) like main.cpp:445-455.  omp=True runs the threaded build;
+    coarse_exact=True is the extension that solves a coarsest grid other than 3x3 exactly."""
     f = _f64(f)
     v = _f64(v).copy(order="F")
     res = np.zeros(Nv + 1)
     tim = np.zeros(Nv + 1)
-    rc = (lib_omp() if omp else lib()).mgo_multigrid(_ptr(f), _ptr(v), f.shape[0], dx, Nv, Ndown, Nup, omega, coarsest,
-                             int(bool(pure_jacobi)), _ptr(res), _ptr(tim))
+    rc = (lib_omp() if omp else lib()).mgo_multigrid_opt(_ptr(f), _ptr(v), f.shape[0], dx, Nv, Ndown, Nup, omega,
+                                                         coarsest, int(bool(pure_jacobi)), int(bool(coarse_exact)),
+                                                         _ptr(res), _ptr(tim))
     if rc != 0:
         raise ValueError("oracle refused the hierarchy (rc=%d)" % rc)
     return v, res, tim

@@ -209,3 +209,50 @@ def test_threaded_oracle_build_returns_the_same_bits(O):
         assert_bits(a[0], b[0], "Sol")
         assert_bits(a[1], b[1], "ResNorms")
     assert O.lib_omp().mgo_threads() >= 1
+
+
+@pytest.mark.parametrize("m", [4, 5, 6, 9, 12, 17, 33, 65])
+def test_exact_coarse_solve_matches_the_references_eigen_cholesky(O, m):
+    """EXTENSION oracle: the banded Cholesky of mgo_coarse_exact against
+    Eigen::SimplicialCholesky on the same 5-point system (main.cpp:79-120), built from the
+    Eigen the reference vendors (oracle/_ref/libeigenref.so)."""
+    if O.ref_eigen() is None:
+        pytest.skip("oracle/_ref/libeigenref.so not built (reference checkout absent)")
+    rng = np.random.default_rng(m)
+    f = np.asfortranarray(rng.standard_normal((m, m)))
+    u = np.asfortranarray(rng.standard_normal((m, m)))
+    dx = 1.0 / (m - 1)
+    a = O.coarse_exact(u, f, dx)
+    b = O.coarse_exact(u, f, dx, eigen=True)
+    assert np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
+    # boundary untouched, interior residual at rounding level (amplified by 1/h^2)
+    assert_bits(a[0, :], u[0, :], "boundary")
+    assert_bits(a[:, -1], u[:, -1], "boundary")
+    r = O.residual(a, f, dx)
+    assert np.abs(r[1:-1, 1:-1]).max() <= 1e-11 * (np.abs(f).max() + np.abs(u).max() / dx ** 2)
+
+
+def test_exact_coarse_solve_3x3_equals_the_closed_form(O):
+    rng = np.random.default_rng(0)
+    f = np.asfortranarray(rng.standard_normal((3, 3)))
+    u = np.asfortranarray(rng.standard_normal((3, 3)))
+    a = O.coarse_exact(u, f, 0.5)
+    b, rc = O.direct_solve(u, f, 0.5)
+    assert rc == 0 and abs(a[1, 1] - b[1, 1]) <= 4e-16 * abs(b[1, 1])
+
+
+def test_even_coarsest_level_is_a_legal_hierarchy(O):
+    """177 = 11*2^4 + 1 with coarsest 11: levels 177, 89, 45, 23, 12.  coarsen() and refine()
+    stay in range between 23 and 12 points (main.cpp:212-219,231-247), so the reference
+    accepts it; an even level ABOVE the coarsest does not work."""
+    from multigrid_amd import rhs
+    M = 177
+    assert O.depth(M, 11) == 4
+    f = rhs.random_np(M)
+    v0 = np.zeros((M, M), order="F")
+    sol, rn, _ = O.multigrid(f, v0, 1.0 / (M - 1), 3, 2, 2, 0.6, 11)
+    assert np.all(np.isfinite(rn)) and rn[3] < rn[0]
+    sol2, rn2, _ = O.multigrid(f, v0, 1.0 / (M - 1), 3, 2, 2, 0.6, 11, coarse_exact=True)
+    assert rn2[3] < 0.2 * rn[3]  # an exact coarsest solve converges much faster
+    with pytest.raises(ValueError):
+        O.multigrid(rhs.random_np(91), np.zeros((91, 91), order="F"), 1.0 / 90, 1, 2, 2, 0.6, 2)  # 91, 46, 23, ...
