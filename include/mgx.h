@@ -142,6 +142,17 @@ int mgx_plan_download(mgx_plan *plan, double *v_host);
 int mgx_plan_cycles(mgx_plan *plan, int Nv, int Ndown, int Nup, double omega, int pure_jacobi,
                     double *resnorms, double *times);
 
+/* EXTENSION (the reference has no full-multigrid driver): nested iteration with the
+ * reference's own operators.  The right-hand side is restricted to every level
+ * (coarsen, main.cpp:201-221), the Dirichlet values of v are injected (coarse boundary
+ * point k <- fine boundary point 2k), the coarsest grid is solved (options.coarse_solve),
+ * and on the way up every level starts from refine() (main.cpp:223-253) of the level
+ * below and runs ncyc V(Ndown,Nup) cycles of MultiGrid() on the hierarchy below it.  The
+ * interior of v on entry is ignored.  resnorms/times (ncyc+1 each, or NULL): the history of
+ * the finest level's cycles.  Synchronous like mgx_plan_cycles(); bit-identical to the same
+ * composition of the reference's operators on the CPU. */
+int mgx_plan_fmg(mgx_plan *plan, int ncyc, int Ndown, int Nup, double omega, double *resnorms, double *times);
+
 /* Per-launch timing of the FINE-LEVEL kernels, for roofline reporting: when
  * enabled, every level-0 kernel launch inside mgx_plan_cycles() is bracketed by
  * two HIP events on the plan's stream; the totals accumulate per kernel id

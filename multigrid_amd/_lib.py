@@ -83,6 +83,7 @@ SIGNATURES = {
     "mgx_plan_download": (ctypes.c_int, [_vp, _vp]),
     "mgx_plan_cycles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_int, _vp, _vp]),
+    "mgx_plan_fmg": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, _vp, _vp]),
     "mgx_relax": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double, _vp]),
     "mgx_residual": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, _vp]),
     "mgx_restrict": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vp]),

@@ -747,6 +747,65 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
     return MGX_OK;
 }
 
+int mgx_plan_fmg(mgx_plan *p, int ncyc, int Ndown, int Nup, double omega, double *resnorms, double *times)
+{
+    if (!p) return fail(MGX_ERR_ARG, "mgx_plan_fmg: null plan");
+    if (ncyc < 0 || Ndown < 0 || Nup < 0) return fail(MGX_ERR_ARG, "mgx_plan_fmg: negative count");
+    hipStream_t s = p->stream;
+    const int depth = p->depth;
+    // right-hand side and Dirichlet values of every level
+    for (int d = 1; d <= depth; d++) {
+        Level &L = p->lv[d - 1];
+        Level &C = p->lv[d];
+        HIP_TRY(launch_restrict(L.f, L.m, C.f, C.m, 1, C.m - 1, 0, 0, s));
+        HIP_TRY(hipMemsetAsync(C.v[0], 0, sizeof(double) * C.n(), s));
+        HIP_TRY(launch_inject_boundary(L.v[L.cur], L.m, C.v[0], C.m, s));
+        HIP_TRY(hipMemcpyAsync(C.v[1], C.v[0], sizeof(double) * C.n(), hipMemcpyDeviceToDevice, s));
+        C.cur = 0;
+    }
+    if (depth > 0) {
+        int rc = coarsest_solve(p);
+        if (rc) return rc;
+    }
+    for (int l = depth > 0 ? depth - 1 : 0; l >= 0; l--) {
+        Level &L = p->lv[l];
+        if (depth > 0) {
+            Level &C = p->lv[l + 1];
+            // initial guess: the interpolated solution of the level below; boundary values stay
+            HIP_TRY(launch_refine(C.v[C.cur], C.m, L.v[L.cur], L.m, 1, L.m - 1, 0, 0, 0, s));
+            // from here on level l+1 holds coarse-grid corrections: zero, with a zero boundary
+            HIP_TRY(hipMemsetAsync(C.v[0], 0, sizeof(double) * C.n(), s));
+            HIP_TRY(hipMemsetAsync(C.v[1], 0, sizeof(double) * C.n(), s));
+            C.cur = 0;
+        }
+        // ncyc cycles of MultiGrid() on the hierarchy that starts at level l: a view of this plan
+        mgx_plan view;
+        view.device = p->device;
+        view.stream = p->stream;
+        view.schedule = p->schedule;
+        view.verbose = p->verbose;
+        view.coarsest = p->coarsest;
+        view.depth = depth - l;
+        view.coarse_solve = p->coarse_solve;
+        view.exact_tables = p->exact_tables;
+        view.use_tail = p->use_tail;
+        view.lv.assign(p->lv.begin() + l, p->lv.end());
+        view.r = p->r;
+        view.slots = p->slots;
+        view.nslots = p->nslots;
+        view.events.swap(p->events);
+        const bool top = l == 0;
+        const int rc = mgx_plan_cycles(&view, ncyc, Ndown, Nup, omega, 0, top ? resnorms : nullptr,
+                                       top ? times : nullptr);
+        p->events.swap(view.events);
+        p->slots = view.slots;
+        p->nslots = view.nslots;
+        for (int k = l; k <= depth; k++) p->lv[k] = view.lv[k - l];  // buffers may have traded places
+        if (rc) return rc;
+    }
+    return MGX_OK;
+}
+
 int mgx_solve2d(const double *f, double *v, int m, int n, double dx,
                 int Nv, int Ndown, int Nup, double omega, int coarsest, int pure_jacobi,
                 double *resnorms, double *times, const mgx_options *opt)

@@ -193,6 +193,28 @@ hipError_t launch_direct3x3(double *v, const double *f, double h2, hipStream_t s
 }
 
 // ---------------------------------------------------------------------------
+// Full-multigrid set-up (an extension, not in the reference): the Dirichlet
+// values of a coarse level are those of the next finer one at the coinciding
+// points, coarse boundary point k <- fine boundary point 2k.
+// ---------------------------------------------------------------------------
+__global__ void k_inject_boundary(const double *__restrict__ fine, int mf, double *__restrict__ coarse, int mc)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= mc) return;
+    const size_t lf = (size_t)mf, lc = (size_t)mc;
+    coarse[0 + k * lc] = fine[0 + (size_t)(2 * k) * lf];
+    coarse[(lc - 1) + k * lc] = fine[(lf - 1) + (size_t)(2 * k) * lf];
+    coarse[k + 0 * lc] = fine[(size_t)(2 * k) + 0 * lf];
+    coarse[k + (lc - 1) * lc] = fine[(size_t)(2 * k) + (lf - 1) * lf];
+}
+
+hipError_t launch_inject_boundary(const double *fine, int mf, double *coarse, int mc, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_inject_boundary, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, s, fine, mf, coarse, mc);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Infinity norm, reference main.cpp:147-150 over DTDoubleArray.cpp:883-899,
 // 923-939: max(Maximum(a), -Minimum(a)) == max |a_k| over the non-NaN entries
 // (-inf if there are none).  max is exact and associative, so any reduction

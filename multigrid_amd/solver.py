@@ -281,6 +281,35 @@ class Plan:
                                            res.ctypes.data, tim.ctypes.data))
         return MGOutputs(res, tim)
 
+    def fmg(self, ncyc, Ndown, Nup, omega):
+        """EXTENSION (not in the reference): full multigrid -- the right-hand side restricted to
+        every level, the coarsest grid solved, then ncyc V(Ndown,Nup) cycles per level on the way
+        up, each level starting from the interpolated solution of the one below.  Only the
+        boundary values of v are used.  Returns the finest level's MGOutputs (ncyc+1 entries)."""
+        res = np.zeros(ncyc + 1)
+        tim = np.zeros(ncyc + 1)
+        _lib.check(self._L.mgx_plan_fmg(self._h, ncyc, Ndown, Nup, omega, res.ctypes.data, tim.ctypes.data))
+        return MGOutputs(res, tim)
+
+
+def FullMultiGrid(prob, ncyc, Ndown, Nup, omega, coarsest, schedule=_lib.SCHEDULE_DEFAULT,
+                  coarse_solve=_lib.COARSE_REFERENCE):
+    """EXTENSION: Plan.fmg() on a gridtype; prob.v (boundary values in, interior ignored) is
+    overwritten with the result."""
+    _require_gpu()
+    m = _square_odd(prob.f, "prob.f")
+    if _square_odd(prob.v, "prob.v") != m:
+        raise ValueError("f and v differ in size")
+    plan = Plan(m, prob.dx, coarsest, schedule, coarse_solve=coarse_solve)
+    try:
+        plan.set(prob.f, prob.v)
+        out = plan.fmg(ncyc, Ndown, Nup, omega)
+        plan.get(out=prob.v)
+        torch.cuda.current_stream().synchronize()
+    finally:
+        plan.close()
+    return out
+
 
 def MultiGrid(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi=False, schedule=_lib.SCHEDULE_DEFAULT,
               coarse_solve=_lib.COARSE_REFERENCE):

@@ -370,6 +370,9 @@ int mgo_multigrid(const double *f, double *v, int m, double dx, int Nv, int Ndow
     return mgo_multigrid_opt(f, v, m, dx, Nv, Ndown, Nup, omega, coarsest, pure_jacobi, 0, resnorm, times);
 }
 
+static int multigrid_core(const double *f, double *v, int m, double dx, int Nv, int Ndown, int Nup, double omega,
+                          int depth, int pure_jacobi, int coarse_exact, double *resnorm, double *times);
+
 int mgo_multigrid_opt(const double *f, double *v, int m, double dx, int Nv, int Ndown, int Nup,
                       double omega, int coarsest, int pure_jacobi, int coarse_exact, double *resnorm,
                       double *times)
@@ -377,6 +380,13 @@ int mgo_multigrid_opt(const double *f, double *v, int m, double dx, int Nv, int 
     if (m < 3 || (m % 2) == 0 || coarsest < 1) return -1;
     int depth = mgo_depth(m, coarsest);
     if (depth < 0) return -2;
+    return multigrid_core(f, v, m, dx, Nv, Ndown, Nup, omega, depth, pure_jacobi, coarse_exact, resnorm, times);
+}
+
+/* The body of MultiGrid() for a given number of coarsenings (main.cpp:288-357). */
+static int multigrid_core(const double *f, double *v, int m, double dx, int Nv, int Ndown, int Nup, double omega,
+                          int depth, int pure_jacobi, int coarse_exact, double *resnorm, double *times)
+{
     int *dims = (int *)malloc((size_t)(depth + 1) * sizeof(int));
     double *hs = (double *)malloc((size_t)(depth + 1) * sizeof(double));
     dims[0] = m;
@@ -438,5 +448,70 @@ int mgo_multigrid_opt(const double *f, double *v, int m, double dx, int Nv, int 
     }
     for (int d = 1; d <= depth; d++) { free(F[d]); free(V[d]); }
     free(F); free(V); free(res); free(refined); free(dims); free(hs);
+    return 0;
+}
+
+/* EXTENSION (not in the reference): full multigrid (nested iteration) composed of the
+ * operators above.  The right-hand side is restricted to every level with coarsen(), the
+ * Dirichlet values of v are injected (coarse boundary point k <- fine boundary point 2k),
+ * the coarsest grid is solved (direct_solve, or mgo_coarse_exact with coarse_exact), and
+ * on the way up each level starts from refine() of the level below and runs ncyc
+ * V(Ndown,Nup) cycles of MultiGrid() on its own sub-hierarchy.  The interior of v on
+ * entry is ignored.  resnorm[0..ncyc] is the residual history of the finest level's
+ * cycles.  Same refusals as mgo_multigrid. */
+int mgo_fmg(const double *f, double *v, int m, double dx, int ncyc, int Ndown, int Nup, double omega,
+            int coarsest, int coarse_exact, double *resnorm)
+{
+    if (m < 3 || (m % 2) == 0 || coarsest < 1) return -1;
+    int depth = mgo_depth(m, coarsest);
+    if (depth < 0) return -2;
+    int *dims = (int *)malloc((size_t)(depth + 1) * sizeof(int));
+    double *hs = (double *)malloc((size_t)(depth + 1) * sizeof(double));
+    dims[0] = m;
+    hs[0] = dx;
+    for (int d = 1; d <= depth; d++) {
+        dims[d] = (dims[d - 1] - 1) / 2 + 1;
+        hs[d] = hs[d - 1] * 2.0;
+    }
+    for (int d = 1; d <= depth; d++)
+        if (dims[d] < 3 || ((dims[d] % 2) == 0 && d < depth)) { free(dims); free(hs); return -3; }
+    double **F = (double **)calloc((size_t)(depth + 1), sizeof(double *));
+    double **V = (double **)calloc((size_t)(depth + 1), sizeof(double *));
+    F[0] = (double *)f;
+    V[0] = v;
+    for (int d = 1; d <= depth; d++) {
+        int mc = dims[d], mf = dims[d - 1];
+        F[d] = (double *)calloc((size_t)mc * mc, sizeof(double));
+        V[d] = (double *)calloc((size_t)mc * mc, sizeof(double));
+        mgo_coarsen(F[d - 1], mf, F[d], mc);
+        for (int k = 0; k < mc; k++) {
+            V[d][IDX(0, k, mc)] = V[d - 1][IDX(0, 2 * k, mf)];
+            V[d][IDX(mc - 1, k, mc)] = V[d - 1][IDX(mf - 1, 2 * k, mf)];
+            V[d][IDX(k, 0, mc)] = V[d - 1][IDX(2 * k, 0, mf)];
+            V[d][IDX(k, mc - 1, mc)] = V[d - 1][IDX(2 * k, mf - 1, mf)];
+        }
+    }
+    double *rn = (double *)malloc((size_t)(ncyc + 1) * sizeof(double));
+    double *tm = (double *)malloc((size_t)(ncyc + 1) * sizeof(double));
+    double *refined = (double *)malloc((size_t)m * (size_t)m * sizeof(double));
+    if (depth == 0) {
+        /* a single level: MultiGrid() on it is the coarsest solve, ncyc times */
+        multigrid_core(F[0], V[0], m, dx, ncyc, Ndown, Nup, omega, 0, 0, coarse_exact, rn, tm);
+    } else {
+        if (coarse_exact && dims[depth] != 3)
+            mgo_coarse_exact(V[depth], F[depth], dims[depth], hs[depth]);
+        else
+            mgo_direct_solve(V[depth], F[depth], dims[depth], hs[depth], 1);
+        for (int d = depth - 1; d >= 0; d--) {
+            int mf = dims[d], mc = dims[d + 1];
+            mgo_refine(V[d + 1], mc, refined, mf);
+            for (int j = 1; j < mf - 1; j++)
+                for (int i = 1; i < mf - 1; i++) V[d][IDX(i, j, mf)] = refined[IDX(i, j, mf)];
+            multigrid_core(F[d], V[d], mf, hs[d], ncyc, Ndown, Nup, omega, depth - d, 0, coarse_exact, rn, tm);
+        }
+    }
+    for (int k = 0; k <= ncyc; k++) resnorm[k] = rn[k];
+    for (int d = 1; d <= depth; d++) { free(F[d]); free(V[d]); }
+    free(F); free(V); free(rn); free(tm); free(refined); free(dims); free(hs);
     return 0;
 }

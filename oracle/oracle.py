@@ -77,6 +77,9 @@ def _load(name):
     L.mgo_multigrid_opt.restype = ctypes.c_int
     L.mgo_multigrid_opt.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp]
+    L.mgo_fmg.restype = ctypes.c_int
+    L.mgo_fmg.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                          ctypes.c_double, ctypes.c_int, ctypes.c_int, _dp]
     L.mgo_multigrid.restype = ctypes.c_int
     L.mgo_multigrid.argtypes = [_dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, _dp, _dp]
@@ -195,3 +198,16 @@ def multigrid(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pure_jacobi=False, om
     if rc != 0:
         raise ValueError("oracle refused the hierarchy (rc=%d)" % rc)
     return v, res, tim
+
+
+def fmg(f, v, dx, ncyc, Ndown, Nup, omega, coarsest=2, coarse_exact=False):
+    """EXTENSION: full multigrid composed of the oracle's operators.  Returns (Sol, ResNorms)
+    with ResNorms the history of the finest level's ncyc cycles."""
+    f = _f64(f)
+    v = _f64(v).copy(order="F")
+    res = np.zeros(ncyc + 1)
+    rc = lib().mgo_fmg(_ptr(f), _ptr(v), f.shape[0], dx, ncyc, Ndown, Nup, omega, coarsest, int(bool(coarse_exact)),
+                       _ptr(res))
+    if rc != 0:
+        raise ValueError("oracle refused the hierarchy (rc=%d)" % rc)
+    return v, res
