@@ -93,7 +93,7 @@ def cycle_bytes(M, depth, nd, nu):
     return tot + 16.0 * M * M
 
 
-def cpu_baseline(M, nd, nu, omega, omp=False):
+def cpu_baseline(M, nd, nu, omega, omp=False, coarsest=2, exact=False):
     """Time the CPU oracle on V-cycles of the same workload: the plain restatement on one
     thread (the reference is single-threaded), or its OpenMP build on the host cores this
     process may use."""
@@ -106,9 +106,9 @@ def cpu_baseline(M, nd, nu, omega, omp=False):
     v = np.zeros((M, M), order="F")
     ncyc = 4 if omp else 1
     if omp:
-        O.multigrid(f, v, 1.0 / (M - 1), 1, nd, nu, omega, 2, omp=True)  # first touch of the pages
+        O.multigrid(f, v, 1.0 / (M - 1), 1, nd, nu, omega, coarsest, omp=True, coarse_exact=exact)  # first touch
     t0 = time.perf_counter()
-    O.multigrid(f, v, 1.0 / (M - 1), ncyc, nd, nu, omega, 2, omp=omp)
+    O.multigrid(f, v, 1.0 / (M - 1), ncyc, nd, nu, omega, coarsest, omp=omp, coarse_exact=exact)
     dt = time.perf_counter() - t0
     return {"value": M * M * ncyc / dt, "unit": "DOF/s", "cores": cores, "kind": "port",
             "sample": "%d V(%d,%d) cycle(s) at %dx%d incl. the residual-norm passes, %.1f s"
@@ -128,6 +128,12 @@ def main():
     ap.add_argument("--slab", action="store_true", help="run the j-slab driver even on one GPU")
     ap.add_argument("--tail-m", type=int, default=0,
                     help="slab driver: largest replicated (tail) level size; 0 = 2049 on one rank, 1025 on more")
+    ap.add_argument("--coarsest", type=int, default=2, help="the reference's -c (threshold for the direct solver)")
+    ap.add_argument("--exact-coarse", action="store_true",
+                    help="extension: solve a coarsest grid other than 3x3 exactly (needed for --coarsest != 2)")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: ~16385^2 points per GPU (16385, 22529, 32769, 45057 per side on 1/2/4/8 "
+                         "GPUs; the sizes 11*2^k+1 use --coarsest 11 --exact-coarse)")
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
     ap.add_argument("--cpu-size", type=int, default=0, help="grid size for the CPU baseline (0 = --size)")
     args = ap.parse_args()
@@ -159,18 +165,26 @@ def main():
     import multigrid_amd as mg
     from multigrid_amd import rhs
 
+    if args.weak:
+        sizes = {1: (16385, 2), 2: (22529, 11), 4: (32769, 2), 8: (45057, 11)}
+        if world not in sizes:
+            sys.exit("bench.py: --weak is defined for 1, 2, 4 or 8 GPUs")
+        args.size, args.coarsest = sizes[world]
+        args.exact_coarse = args.exact_coarse or args.coarsest != 2
     M, K, W = args.size, args.steps, args.warmup
     dx = 1.0 / (M - 1)
+    coarse_solve = mg.COARSE_EXACT if args.exact_coarse else mg.COARSE_REFERENCE
 
     if world == 1 and not args.slab:
-        plan = mg.Plan(M, dx, 2, schedule=args.schedule)
+        plan = mg.Plan(M, dx, args.coarsest, schedule=args.schedule, coarse_solve=coarse_solve)
         plan.set(rhs.random_torch(M), mg.colmajor(M, M))
         solver = plan
         depth = plan.depth
         schedule_name = "single-gpu"
     else:
         from multigrid_amd import slab
-        solver = slab.SlabSolver(M, dx, 2, schedule=args.schedule, tail_m=args.tail_m)
+        solver = slab.SlabSolver(M, dx, args.coarsest, schedule=args.schedule, tail_m=args.tail_m,
+                                 coarse_solve=coarse_solve)
         solver.set_random_rhs()
         depth = solver.depth
         schedule_name = "j-slabs x%d, %d distributed levels, replicated tail from %d^2" % (
@@ -229,9 +243,11 @@ def main():
             "metric": "fine-grid DOF/s per V-cycle (fp64)",
             "value": value, "unit": "DOF/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "2D Poisson 5-point %dx%d fp64 V(%d,%d), omega %.2f, coarsest 2, random RHS, "
-                                   "zero guess, %d levels" % (M, M, args.nd, args.nu, args.omega, depth + 1),
+            "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2D Poisson 5-point %dx%d fp64 V(%d,%d), omega %.2f, coarsest %d%s, random RHS, "
+                                   "zero guess, %d levels" % (M, M, args.nd, args.nu, args.omega, args.coarsest,
+                                                              " (exact coarsest solve)" if args.exact_coarse else "",
+                                                              depth + 1),
                        "M": M, "decomposition": schedule_name, "schedule": args.schedule},
             "cycle_algorithmic_GB": B / 1e9,
             "cycle_algorithmic_GBps": B * K / elapsed / 1e9,
@@ -241,8 +257,10 @@ def main():
         }
         if world == 1 and args.cpu_baseline == "auto":
             try:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega)
-                line["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega, omp=True)
+                line["cpu_baseline"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega, False,
+                                                    args.coarsest, args.exact_coarse)
+                line["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega, True,
+                                                              args.coarsest, args.exact_coarse)
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "DOF/s", "cores": 1, "kind": "port",
                                         "sample": "failed: %r" % (e,)}

@@ -58,3 +58,29 @@ def test_fmg_with_exact_coarsest_solve(mg, O):
     out = mg.FullMultiGrid(prob, 2, 2, 2, 0.6, 11, coarse_solve=mg.COARSE_EXACT)
     assert np.allclose(out.ResidualNorms, rn, rtol=1e-6, atol=1e-9 * rn[0])
     assert np.abs(mg.to_numpy(prob.v) - sol).max() <= 1e-9 * np.abs(sol).max()
+
+
+def test_fmg_plus_vcycles_at_32769_schedules_agree(mg):
+    """BASELINE config 5 (FMG + V-cycles on 32769^2): far too big for the CPU oracle in
+    seconds, so the two independent GPU schedules must agree bit for bit, FMG must start the
+    finest level well below the zero-guess residual, and the V-cycles after it must contract."""
+    import torch
+    from multigrid_amd import rhs
+    M = 32769
+    dx = 1.0 / (M - 1)
+    f = rhs.random_torch(M)
+    res = []
+    for sched in (mg.SCHEDULE_STEPWISE, mg.SCHEDULE_FUSED):
+        plan = mg.Plan(M, dx, 2, schedule=sched)
+        plan.set(f, mg.colmajor(M, M))
+        zero_guess_norm = plan.cycles(0, 2, 2, 0.6).ResidualNorms[0]
+        a = plan.fmg(1, 2, 2, 0.6)
+        b = plan.cycles(3, 2, 2, 0.6)
+        res.append((a.ResidualNorms, b.ResidualNorms, plan.get().clone()))
+        plan.close()
+        assert a.ResidualNorms[1] < 0.2 * zero_guess_norm
+        assert b.ResidualNorms[0] == a.ResidualNorms[1]
+        assert b.ResidualNorms[3] < 0.1 * b.ResidualNorms[0]
+    assert_bits(res[0][0], res[1][0], "FMG ResNorms")
+    assert_bits(res[0][1], res[1][1], "V-cycle ResNorms")
+    assert torch.equal(res[0][2].view(torch.int64), res[1][2].view(torch.int64))
