@@ -1,9 +1,10 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 600 python -u -m pytest tests/test_gpu_fmg.py -x -q --timeout 300 --timeout-method thread -k 32769 2>&1 | tail -15
-timeout -k 10 200 python bench.py --size 22529 --coarsest 11 --exact-coarse --steps 20 --cpu-baseline off > gpurun_out/b22529.json
-python3 -c "import json; d=json.load(open('gpurun_out/b22529.json')); print(d['ms_per_step'], d['value']/1e9, d['config']['workload'], d['resnorm_first_last'])"
-timeout -k 10 200 python bench.py --size 22529 --coarsest 11 --exact-coarse --steps 20 --cpu-baseline off --slab > gpurun_out/b22529s.json
-python3 -c "import json; d=json.load(open('gpurun_out/b22529s.json')); print(d['ms_per_step'], d['value']/1e9, d['config']['decomposition'], d['resnorm_first_last'])"
-timeout -k 10 200 python bench.py --size 32769 --steps 20 --cpu-baseline off > gpurun_out/b32769.json
-python3 -c "import json; d=json.load(open('gpurun_out/b32769.json')); print(d['ms_per_step'], d['value']/1e9, d['resnorm_first_last'])"
+export TMPDIR=/tmp
+R=$PWD
+rm -rf gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/kt
+timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_f -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > gpurun_out/pmc_f.log 2>&1
+timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_w -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > gpurun_out/pmc_w.log 2>&1
+timeout -s KILL 180 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt -o kt --output-format csv -- python3 bench.py --steps 20 --warmup 3 --cpu-baseline off > gpurun_out/kt.log 2>&1
+timeout -k 10 300 python bench.py > gpurun_out/bench_default.json
+tail -c 700 gpurun_out/bench_default.json
