@@ -1,0 +1,79 @@
+// ref_dt_dropin.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// The reference-side binding of libmgx, compiled against the reference's REAL DTSource
+// containers (the sources are compiled where they lie, oracle/Makefile; output in
+// oracle/_ref/).  It is what a maintainer of the reference would have after swapping the
+// body of MultiGrid() (main.cpp:283-357) for one call into the C ABI: the same
+// gridtype / MGOutputs aggregates (main.cpp:29-40), DTMatlabDataFile for Input.mat and
+// Output.mat (main.cpp:391-396,452-455), a zero initial guess with boundary_func == 0 on
+// the boundary (main.cpp:420-439).  Option parsing is positional here because the
+// reference's uses boost, which the image lacks:
+//     dt_dropin Nv Ndown Nup omega coarsest   (cwd holds Input.mat; writes Output.mat)
+// tests/test_gpu_dropin.py runs it on the GPU box and compares Output.mat with the oracle.
+#include "DTDoubleArray.h"
+#include "DTMatlabDataFile.h"
+#include "DTMesh2D.h"
+#include "DTMesh2DGrid.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "mgx.h"
+
+// the two aggregates MultiGrid() trades in (main.cpp:29-40)
+struct gridtype {
+    DTMutableMesh2D f;  // right-hand side
+    DTMutableMesh2D v;  // initial guess in, solution out
+};
+
+struct MGOutputs {
+    DTDoubleArray ResidualNorms;
+    DTDoubleArray Times;
+    MGOutputs(DTDoubleArray r, DTDoubleArray t) : ResidualNorms(r), Times(t) {}
+};
+
+// Drop-in for main.cpp:283: same signature, same in-place solution, same two output vectors.
+MGOutputs MultiGrid(gridtype &prob, int Nv, int Ndown, int Nup, double omega, int coarsest, bool pureJacobi = false)
+{
+    DTMutableDoubleArray v = prob.v.DoubleData();  // shares storage with prob.v (main.cpp:288)
+    DTMutableDoubleArray f = prob.f.DoubleData();
+    DTMutableDoubleArray resnorm(Nv + 1), times(Nv + 1);
+    const int rc = mgx_solve2d(f.Pointer(), v.Pointer(), (int)v.m(), (int)v.n(), prob.v.Grid().dx(), Nv, Ndown, Nup,
+                               omega, coarsest, pureJacobi ? 1 : 0, resnorm.Pointer(), times.Pointer(), NULL);
+    if (rc != MGX_OK) {
+        printf("Error: %s\n", mgx_last_error());
+        exit(1);
+    }
+    return MGOutputs(resnorm, times);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 6) {
+        fprintf(stderr, "usage: dt_dropin Nv Ndown Nup omega coarsest\n");
+        return 2;
+    }
+    const int Nv = atoi(argv[1]), Ndown = atoi(argv[2]), Nup = atoi(argv[3]), coarsest = atoi(argv[5]);
+    const double omega = atof(argv[4]);
+
+    DTMatlabDataFile inputFile("Input.mat", DTFile::ReadOnly);
+    DTMesh2D f;
+    Read(inputFile, "f", f);
+    DTMesh2DGrid grid = f.Grid();
+    DTDoubleArray fData = f.DoubleData();
+    const int M = (int)fData.m(), N = (int)fData.n();
+
+    DTMutableDoubleArray u(M, N);
+    u = 0;  // zero guess, zero Dirichlet data (boundary_func, main.cpp:43-47)
+
+    gridtype problem;
+    problem.f = DTMutableMesh2D(grid, fData.Copy());
+    problem.v = DTMutableMesh2D(grid, u.Copy());
+    MGOutputs output = MultiGrid(problem, Nv, Ndown, Nup, omega, coarsest, false);
+
+    DTMatlabDataFile outputFile("Output.mat", DTFile::NewReadWrite);
+    outputFile.Save(problem.v.DoubleData(), "Sol");
+    outputFile.Save(output.ResidualNorms, "ResNorms");
+    outputFile.Save(output.Times, "Times");
+    return 0;
+}

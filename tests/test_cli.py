@@ -110,3 +110,19 @@ def test_unsupported_coarsest_prints_the_reference_message(tmp_path):
     rc, out = run(["-v", "2", "-c", "4"], tmp_path)
     assert rc == 0
     assert "Error: Direct solver not defined for 5x5 matrices!" in out               # main.cpp:167
+
+
+@pytest.mark.gpu
+def test_exact_coarse_flag(O, tmp_path):
+    """--exact-coarse (an extension): -c 4 ends on a 5x5 grid, which is then solved exactly."""
+    from multigrid_amd import rhs
+    M = 129
+    h = 1.0 / (M - 1)
+    f = rhs.random_np(M)
+    mat4.write(tmp_path / "Input.mat", [("f", f), ("f_loc", np.array([[0.0, 0.0, h, h]]))])
+    rc, out = run(["-v", "5", "-b", "2", "-a", "2", "-c", "4", "--exact-coarse"], tmp_path)
+    assert rc == 0 and "Direct solver not defined" not in out, out
+    res = mat4.read(tmp_path / "Output.mat")
+    sol, rn, _ = O.multigrid(f, np.zeros((M, M), order="F"), h, 5, 2, 2, 0.6, 4, coarse_exact=True)
+    assert np.allclose(res["ResNorms"].ravel(), rn, rtol=1e-6, atol=1e-9 * rn[0])
+    assert np.abs(res["Sol"] - sol).max() <= 1e-9 * np.abs(sol).max()
