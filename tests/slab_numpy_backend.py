@@ -50,8 +50,9 @@ class NumpyBackend:
     name = "numpy"
     device = None
 
-    def __init__(self, oracle):
+    def __init__(self, oracle, coarse_exact=False):
         self.O = oracle
+        self.coarse_exact = coarse_exact
 
     def zeros(self, ncols, m):
         return np.zeros((ncols, m))
@@ -84,7 +85,7 @@ class NumpyBackend:
         pass
 
     def make_tail(self, m, dx, coarsest):
-        return _OracleTail(self.O, m, dx, coarsest)
+        return _OracleTail(self.O, m, dx, coarsest, self.coarse_exact)
 
     def _correction(self, op, ncols, m):
         c = op.coarse_v
@@ -162,15 +163,15 @@ class NumpyBackend:
 
 
 class _OracleTail:
-    def __init__(self, O, m, dx, coarsest):
-        self.O, self.m, self.dx, self.coarsest = O, m, dx, coarsest
+    def __init__(self, O, m, dx, coarsest, coarse_exact=False):
+        self.O, self.m, self.dx, self.coarsest, self.coarse_exact = O, m, dx, coarsest, coarse_exact
         self.f = np.zeros((m, m))  # slab layout: row k = column k
         self.v = np.zeros((m, m))
 
     def run(self, Ndown, Nup, omega):
         f = np.asfortranarray(self.f.T)
         sol, _, _ = self.O.multigrid(f, np.zeros((self.m, self.m), order="F"), self.dx, 1, Ndown, Nup, omega,
-                                     self.coarsest)
+                                     self.coarsest, coarse_exact=self.coarse_exact)
         self.v[:] = sol.T
         return self.v
 

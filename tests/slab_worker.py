@@ -1,7 +1,7 @@
 """One rank of a multi-process SlabSolver test (launched by test_slab_cpu.py and
 test_gpu_slab.py with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set).
 
-  python slab_worker.py <backend: numpy|hip|hip-rccl> <M> <Nv> <Ndown> <Nup> <omega> <tail_m> <pure_jacobi>
+  python slab_worker.py <backend: numpy|hip|hip-rccl> <M> <Nv> <Ndown> <Nup> <omega> <tail_m> <pure_jacobi> [coarsest] [exact_coarse]
 
 Every rank builds the same global problem, solves it with the slab driver over
 gloo and compares the gathered solution and the residual history with the CPU
@@ -21,6 +21,8 @@ def main():
     backend, M, Nv, nd, nu, omega, tail_m, pure = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]),
                                                    int(sys.argv[5]), float(sys.argv[6]), int(sys.argv[7]),
                                                    int(sys.argv[8]))
+    coarsest = int(sys.argv[9]) if len(sys.argv) > 9 else 2
+    exact = bool(int(sys.argv[10])) if len(sys.argv) > 10 else False
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -41,12 +43,12 @@ def main():
     from multigrid_amd import rhs, slab
     if backend == "numpy":
         from slab_numpy_backend import NumpyBackend
-        be = NumpyBackend(O)
+        be = NumpyBackend(O, coarse_exact=exact)
     elif rccl:
-        be = slab.HipBackend()
+        be = slab.HipBackend(coarse_solve=int(exact))
     else:
         torch.cuda.set_device(0)  # every rank shares the one GPU of the test box
-        be = slab.HipBackend()
+        be = slab.HipBackend(coarse_solve=int(exact))
 
     dx = 1.0 / (M - 1)
     f = rhs.random_np(M)
@@ -55,7 +57,7 @@ def main():
     v0[0, :], v0[-1, :], v0[:, 0], v0[:, -1] = rng.standard_normal((4, M))   # non-zero Dirichlet data
     v0[1:-1, 1:-1] = rng.standard_normal((M - 2, M - 2)) * 0.01              # and a non-zero guess
 
-    S = slab.SlabSolver(M, dx, 2, backend=be, tail_m=tail_m, halo=8)
+    S = slab.SlabSolver(M, dx, coarsest, backend=be, tail_m=tail_m, halo=8)
     S.set_problem(f, v0)
     out = S.cycles(Nv, nd, nu, omega, pureJacobi=bool(pure))
     sol = S.gather_solution()
@@ -63,10 +65,16 @@ def main():
 
     ok = True
     if rank == 0:
-        ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, 2, pure_jacobi=bool(pure))
-        same_rn = np.array_equal(out.ResidualNorms.view(np.uint64), ref_rn.view(np.uint64))
-        same_sol = np.array_equal(np.ascontiguousarray(sol).view(np.uint64),
-                                  np.ascontiguousarray(ref_sol).view(np.uint64))
+        ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, coarsest, pure_jacobi=bool(pure),
+                                         coarse_exact=exact)
+        if exact and backend != "numpy":
+            # the GPU's sine-transform solve agrees with the oracle's Cholesky to rounding only
+            same_rn = bool(np.allclose(out.ResidualNorms, ref_rn, rtol=1e-6, atol=1e-9 * ref_rn[0]))
+            same_sol = bool(np.abs(sol - ref_sol).max() <= 1e-9 * np.abs(ref_sol).max())
+        else:
+            same_rn = np.array_equal(out.ResidualNorms.view(np.uint64), ref_rn.view(np.uint64))
+            same_sol = np.array_equal(np.ascontiguousarray(sol).view(np.uint64),
+                                      np.ascontiguousarray(ref_sol).view(np.uint64))
         ok = same_rn and same_sol
         print("slab_worker: world=%d backend=%s M=%d ndist=%d resnorms_equal=%s sol_equal=%s"
               % (world, backend, M, S.ndist, same_rn, same_sol), flush=True)

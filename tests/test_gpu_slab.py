@@ -46,6 +46,13 @@ def test_ranks_share_gpu_over_gloo(O, world, M, tail_m):
     assert "resnorms_equal=True sol_equal=True" in outs[0]
 
 
+def test_ranks_share_gpu_exact_coarse_even_coarsest(O):
+    """705 = 11*2^6+1, coarsest 11: levels ... 23, 12; the tail solves the 12x12 grid exactly."""
+    codes, outs = run_ranks(2, ["hip", 705, 4, 2, 2, 0.6, 89, 0, 11, 1], timeout=400)
+    assert codes == [0, 0], "\n".join(outs)
+    assert "resnorms_equal=True sol_equal=True" in outs[0]
+
+
 def test_rccl_group_of_one_rank(O):
     """The RCCL calls of the multi-GPU path (process group bound to the device, all-gather
     into the tail plan's own buffer, max-reduction of the norm slots) on the one GPU there

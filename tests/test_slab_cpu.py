@@ -103,6 +103,16 @@ def test_gloo_other_sweep_counts_and_pure_jacobi(O):
         assert codes == [0, 0], "\n".join(outs)
 
 
+@pytest.mark.parametrize("world,M,tail_m,exact", [(2, 177, 45, 0), (2, 353, 45, 1), (3, 705, 89, 1), (2, 97, 25, 1)])
+def test_gloo_ranks_other_hierarchies(O, world, M, tail_m, exact):
+    """Sizes 11*2^k+1 with coarsest 11 end on an EVEN 12x12 grid (97 with coarsest 6: 7x7); with the
+    exact coarsest solve (an extension) the replicated tail solves it, otherwise it is left as it is."""
+    coarsest = 6 if M == 97 else 11
+    codes, outs = run_ranks(world, ["numpy", M, 3, 2, 2, 0.6, tail_m, 0, coarsest, exact])
+    assert codes == [0] * world, "\n".join(outs)
+    assert "resnorms_equal=True sol_equal=True" in outs[0]
+
+
 def test_ownership_is_nested_and_covers_every_level(O):
     from multigrid_amd import slab
 
