@@ -94,6 +94,23 @@ struct mgx_plan {
 
 namespace {
 
+// A plan lives on the device it was created on; its entry points run there whatever
+// device the calling thread has current, and put the caller's device back on return.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(const mgx_plan *p)
+    {
+        if (p && hipGetDevice(&prev) == hipSuccess && prev != p->device) switched = hipSetDevice(p->device) == hipSuccess;
+    }
+    ~DeviceScope()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
 int plan_alloc(mgx_plan *p, void **ptr, size_t nbytes)
 {
     HIP_TRY(hipMalloc(ptr, nbytes));
@@ -463,7 +480,20 @@ int mgx_depth(int m, int coarsest)
     return (int)(log2f(ratio) + 0.5f);
 }
 
+static int plan_create_on_device(mgx_plan **out, int m, double dx, int coarsest, const mgx_options *opt);
+
 int mgx_plan_create(mgx_plan **out, int m, double dx, int coarsest, const mgx_options *opt)
+{
+    // options.device selects where the plan lives; the caller's current device is left as it was
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    const int rc = plan_create_on_device(out, m, dx, coarsest, opt);
+    int now = -1;
+    if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev);
+    return rc;
+}
+
+static int plan_create_on_device(mgx_plan **out, int m, double dx, int coarsest, const mgx_options *opt)
 {
     if (!out) return fail(MGX_ERR_ARG, "mgx_plan_create: null output pointer");
     *out = nullptr;
@@ -566,6 +596,7 @@ int mgx_plan_create(mgx_plan **out, int m, double dx, int coarsest, const mgx_op
 
 int mgx_plan_destroy(mgx_plan *p)
 {
+    DeviceScope on_plan_device(p);
     if (!p) return MGX_OK;
     (void)hipStreamSynchronize(p->stream);
     for (Level &L : p->lv) {
@@ -598,6 +629,7 @@ double *mgx_plan_v_dev(mgx_plan *p) { return p ? p->lv[0].v[0] : nullptr; }
 
 int mgx_plan_commit(mgx_plan *p)
 {
+    DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_commit: null plan");
     Level &L = p->lv[0];
     L.cur = 0;
@@ -632,6 +664,7 @@ const char *mgx_kernel_name(int kernel_id)
 
 int mgx_plan_set_dev(mgx_plan *p, const double *f_dev, const double *v_dev)
 {
+    DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_set_dev: null plan");
     Level &L = p->lv[0];
     const size_t nb = sizeof(double) * L.n();
@@ -642,6 +675,7 @@ int mgx_plan_set_dev(mgx_plan *p, const double *f_dev, const double *v_dev)
 
 int mgx_plan_get_dev(mgx_plan *p, double *v_dev)
 {
+    DeviceScope on_plan_device(p);
     if (!p || !v_dev) return fail(MGX_ERR_ARG, "mgx_plan_get_dev: null argument");
     Level &L = p->lv[0];
     HIP_TRY(hipMemcpyAsync(v_dev, L.v[0], sizeof(double) * L.n(), hipMemcpyDeviceToDevice, p->stream));
@@ -650,6 +684,7 @@ int mgx_plan_get_dev(mgx_plan *p, double *v_dev)
 
 int mgx_plan_upload(mgx_plan *p, const double *f_host, const double *v_host)
 {
+    DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_upload: null plan");
     Level &L = p->lv[0];
     const size_t nb = sizeof(double) * L.n();
@@ -663,6 +698,7 @@ int mgx_plan_upload(mgx_plan *p, const double *f_host, const double *v_host)
 
 int mgx_plan_download(mgx_plan *p, double *v_host)
 {
+    DeviceScope on_plan_device(p);
     if (!p || !v_host) return fail(MGX_ERR_ARG, "mgx_plan_download: null argument");
     Level &L = p->lv[0];
     HIP_TRY(hipMemcpyAsync(v_host, L.v[0], sizeof(double) * L.n(), hipMemcpyDeviceToHost, p->stream));
@@ -673,6 +709,7 @@ int mgx_plan_download(mgx_plan *p, double *v_host)
 int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int pure_jacobi,
                     double *resnorms, double *times)
 {
+    DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_cycles: null plan");
     if (Nv < 0 || Ndown < 0 || Nup < 0) return fail(MGX_ERR_ARG, "mgx_plan_cycles: negative count");
     hipStream_t s = p->stream;
@@ -749,6 +786,7 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
 
 int mgx_plan_fmg(mgx_plan *p, int ncyc, int Ndown, int Nup, double omega, double *resnorms, double *times)
 {
+    DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_fmg: null plan");
     if (ncyc < 0 || Ndown < 0 || Nup < 0) return fail(MGX_ERR_ARG, "mgx_plan_fmg: negative count");
     hipStream_t s = p->stream;
@@ -1079,6 +1117,7 @@ double mgx_norm_decode(unsigned long long slot) { return norm_decode(slot); }
 
 int mgx_plan_vcycle_async(mgx_plan *p, int Ndown, int Nup, double omega, int zero_guess)
 {
+    DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_vcycle_async: null plan");
     if (Ndown < 0 || Nup < 0) return fail(MGX_ERR_ARG, "mgx_plan_vcycle_async: negative count");
     if (zero_guess && p->schedule != MGX_SCHEDULE_FUSED) {

@@ -5,6 +5,8 @@
 
 #include <math.h>
 
+#include <atomic>
+
 namespace mgx {
 
 namespace {
@@ -39,15 +41,16 @@ hipError_t launch_coarse_exact(double *u, const double *f, int m, double h2, con
     if (m < 4 || m > COARSE_EXACT_MAX_M) return hipErrorInvalidValue;
     const int n = m - 2;
     const size_t bytes = sizeof(double) * ((size_t)3 * n * n + n);
-    static bool configured[64] = {false};
+    // a launch with more than 64 KB of dynamic LDS must be allowed once per device
+    static std::atomic<unsigned long long> configured{0};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !configured[dev]) {  // up to 96 KB of dynamic LDS: ask once per device
-        e = hipFuncSetAttribute((const void *)k_coarse_exact, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(double) * (3 * 63 * 63 + 63)));
+    const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+    if (!(configured.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute((const void *)k_coarse_exact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (3 * 63 * 63 + 63)));
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) configured[dev] = true;
+        configured.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(k_coarse_exact, dim3(1), dim3(1024), bytes, s, u, f, m, h2, tables);
     return hipGetLastError();

@@ -20,6 +20,8 @@
 #include "mgx_coarse.h"
 #include "mgx_internal.h"
 
+#include <atomic>
+
 namespace mgx {
 
 namespace {
@@ -230,16 +232,16 @@ hipError_t launch_tail(const TailArgs &A0, hipStream_t s)
     A.tables_len = A.exact_tables ? nc * nc + nc : 0;
     const size_t bytes = tail_lds_bytes(A);
     if (bytes > TAIL_MAX_LDS_BYTES) return hipErrorInvalidValue;
-    // more than 64 KB of dynamic LDS must be requested once per device
-    static bool configured[64] = {false};
+    // a launch with more than 64 KB of dynamic LDS must be allowed once per device
+    static std::atomic<unsigned long long> configured{0};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !configured[dev]) {
-        e = hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)TAIL_MAX_LDS_BYTES);
+    const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+    if (!(configured.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute((const void *)k_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAIL_MAX_LDS_BYTES);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) configured[dev] = true;
+        configured.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), bytes, s, A);
     return hipGetLastError();
