@@ -155,6 +155,21 @@ class _HipTail:
         _lib.check(self.be.L.mgx_plan_vcycle_async(self.h, Ndown, Nup, omega, 1))
         return self.v
 
+    def fmg(self, ncyc, Ndown, Nup, omega):
+        """Full multigrid on the tail (mgx_plan_fmg) for the right-hand side in self.f and the
+        boundary values in self.v; returns the result (the plan's iterate buffer may have
+        traded places with its twin, so the view is taken again)."""
+        L = self.be.L
+        _lib.check(L.mgx_plan_commit(self.h))
+        _lib.check(L.mgx_plan_fmg(self.h, ncyc, Ndown, Nup, omega, None, None))
+        self.v = _device_view(L.mgx_plan_v_dev(self.h), self.m, self.be.device)
+        return self.v
+
+    def reset(self):
+        """Zero iterate with zero boundary values: what a cycle's coarse-grid correction starts from."""
+        self.v.zero_()
+        _lib.check(self.be.L.mgx_plan_commit(self.h))
+
     def close(self):
         if self.h:
             self.be.L.mgx_plan_destroy(self.h)
@@ -306,6 +321,19 @@ def halo_capacity(nd):
     return Ev, Ef
 
 
+def view_capacity(nd):
+    """halo_capacity for the hierarchy of nd distributed levels AND for every sub-hierarchy
+    that starts at one of its levels (full multigrid runs cycles on those too)."""
+    Ev = [0] * (nd + 1)
+    Ef = [0] * (nd + 1)
+    for s in range(nd):
+        ev, ef = halo_capacity(nd - s)
+        for j in range(nd - s + 1):
+            Ev[s + j] = max(Ev[s + j], ev[j])
+            Ef[s + j] = max(Ef[s + j], ef[j])
+    return Ev, Ef
+
+
 class SlabSolver:
     """Nv V(Ndown,Nup) cycles of the reference's MultiGrid() on an M x M grid split into j-slabs.
 
@@ -344,7 +372,7 @@ class SlabSolver:
         while nd < self.depth and dims[nd] > tail_m:
             # would every rank still own at least a halo's worth of columns of every
             # level if one more level were distributed?
-            Ev, Ef = halo_capacity(nd + 1)
+            Ev, Ef = view_capacity(nd + 1)
             base = (dims[nd + 1] - 2) // R  # least number of columns a rank owns of the would-be tail top
             fits = base >= 1
             for l in range(nd + 1):
@@ -358,7 +386,7 @@ class SlabSolver:
             raise ValueError("grid %d is not split over %d rank(s) with tail_m=%d: solve it with "
                              "multigrid_amd.MultiGrid on one GPU" % (M, R, tail_m))
         self.ndist = nd
-        Ev_max, Ef_max = halo_capacity(nd)
+        Ev_max, Ef_max = view_capacity(nd)
         mt = dims[nd]
         b = [0] + [1 + (g * (mt - 2)) // R for g in range(1, R)] + [mt]  # ownership on the tail's top level
         bounds = {nd: b}
@@ -589,13 +617,17 @@ class SlabSolver:
 
     def _tail(self, Ndown, Nup, omega):
         """All-gather the tail's right-hand side and run the tail on every rank."""
-        g = self.comm.rank
-        if not self.comm.solo:
-            s = self.tail_start[g]
-            mine = self.tail_f[s:s + self.tail_pad]
-            self.comm.allgather(self.be.comm_tensor(mine), out=self.be.comm_tensor(self.tail_gathered))
-            self.be.take_rows(self.tail_gathered, self.tail_rows, out=self.tail_f)
+        self._gather_tail(self.tail_f)
         return self.tail.run(Ndown, Nup, omega)
+
+    def _gather_tail(self, t):
+        """t: an array of the tail's top level (one row per column) of which every rank holds
+        its own columns; afterwards every rank holds all of them."""
+        if not self.comm.solo:
+            s = self.tail_start[self.comm.rank]
+            mine = t[s:s + self.tail_pad]
+            self.comm.allgather(self.be.comm_tensor(mine), out=self.be.comm_tensor(self.tail_gathered))
+            self.be.take_rows(self.tail_gathered, self.tail_rows, out=t)
 
     # ---- the general schedule: a chain per leg, an exchange after every launch ----------
     def _cycle_general(self, Ndown, Nup, omega, slot):
@@ -731,6 +763,91 @@ class SlabSolver:
         self.comm.allreduce_max_(slots)
         be.synchronize()
         return MGOutputs(be.decode_slots(slots), times)
+
+    # ---- full multigrid (an extension; the reference has no such driver) ------------------
+    def _view(self, l):
+        """This solver restricted to the levels from l downwards: level l becomes level 0."""
+        if l == 0:
+            return self
+        sub = object.__new__(SlabSolver)
+        sub.__dict__.update(self.__dict__)
+        sub.levels = self.levels[l:]
+        sub.ndist = self.ndist - l
+        sub.dims, sub.hs = self.dims[l:], self.hs[l:]
+        sub.M, sub.dx, sub.depth = self.dims[l], self.hs[l], self.depth - l
+        sub.bounds = {k - l: b for k, b in self.bounds.items() if k >= l}
+        sub._prof = False
+        return sub
+
+    @staticmethod
+    def _inject(src, F, dst, c0, c1, row0, mc, first, last):
+        """Dirichlet values of a coarse level from the next finer one, coarse boundary point k
+        <- fine boundary point 2k, for the coarse columns [c0, c1) this rank owns (stored in
+        dst from row `row0` on); src is the fine slab F.  The two physical boundary columns go
+        with the ranks that hold them."""
+        mf = F.m
+        fl0 = 2 * c0 - F.lo
+        n = c1 - c0
+        dst[row0:row0 + n, 0] = src[fl0:fl0 + 2 * n:2, 0]
+        dst[row0:row0 + n, mc - 1] = src[fl0:fl0 + 2 * n:2, mf - 1]
+        if first:
+            dst[row0, :] = src[0, ::2]
+        if last:
+            dst[row0 + n - 1, :] = src[F.ncols - 1, ::2]
+
+    def fmg(self, ncyc, Ndown, Nup, omega):
+        """EXTENSION: full multigrid over the slabs -- the composition mgx_plan_fmg runs on one
+        GPU.  The right-hand side is restricted to every level, the Dirichlet values of v are
+        injected, the replicated tail runs its own full multigrid, and on the way up each
+        distributed level starts from the interpolated solution of the level below and runs
+        ncyc V(Ndown,Nup) cycles on the sub-hierarchy below it.  Only the boundary values of v
+        are used.  Returns the finest level's MGOutputs.  (A coarse value of -0.0 is
+        interpolated as +0.0: the kernel adds the interpolant to a zero iterate.)"""
+        nd = self.ndist
+        R, g = self.comm.size, self.comm.rank
+        for l in range(nd):
+            Lv = self.levels[l]
+            C, cshape = self._coarse_of(l)
+            cf = C.f if C is not None else self.tail_f
+            # the residual of a zero iterate is the right-hand side itself: restriction of f
+            op = self._op(Lv, 0, self._range(Lv), restrict_out=1, zero_in=1, store=0, omega=omega, coarse=cshape,
+                          coarse_f=cf)
+            self._launch(l, "k_stream:down", op)
+            src = Lv.v[Lv.cur]
+            if C is not None:
+                self.comm.exchange([self._xf(C)])
+                C.v[0][...] = 0.0
+                self._inject(src, Lv, C.v[0], C.b0, C.b1, C.o0, C.m, C.lo == 0, C.hi == C.m)
+                self.comm.exchange([(self.be.comm_tensor(C.v[0]),) + self._halo_ranges(C, C.W)])
+                C.v[1][...] = C.v[0]
+                C.cur = 0
+            else:
+                tb = self.bounds[nd]
+                mt = self.dims[nd]
+                tv = self.tail.v
+                tv[...] = 0.0
+                self._inject(src, Lv, tv, tb[g], tb[g + 1], tb[g], mt, g == 0, g == R - 1)
+                self._gather_tail(tv)
+        self._gather_tail(self.tail_f)
+        vt = self.tail.fmg(ncyc, Ndown, Nup, omega)
+        out = None
+        for l in range(nd - 1, -1, -1):
+            Lv = self.levels[l]
+            C, cshape = self._coarse_of(l)
+            cv = C.v[C.cur] if C is not None else vt
+            # initial guess: the interpolated solution of the level below (boundary values stay)
+            op = self._op(Lv, 0, self._range(Lv), pro_stage=0, zero_in=1, store=1, omega=omega, v_out=Lv.v[Lv.cur],
+                          coarse=cshape, coarse_v=cv)
+            self._launch(l, "k_stream:up", op)
+            # from here on the level below holds coarse-grid corrections: zero, zero boundary
+            if C is not None:
+                C.v[0][...] = 0.0
+                C.v[1][...] = 0.0
+                C.cur = 0
+            else:
+                self.tail.reset()
+            out = self._view(l).cycles(ncyc, Ndown, Nup, omega)
+        return out
 
     def close(self):
         if self.tail is not None:

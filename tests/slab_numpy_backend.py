@@ -175,5 +175,15 @@ class _OracleTail:
         self.v[:] = sol.T
         return self.v
 
+    def fmg(self, ncyc, Ndown, Nup, omega):
+        f = np.asfortranarray(self.f.T)
+        sol, _ = self.O.fmg(f, np.asfortranarray(self.v.T), self.dx, ncyc, Ndown, Nup, omega, self.coarsest,
+                            coarse_exact=self.coarse_exact)
+        self.v[:] = sol.T
+        return self.v
+
+    def reset(self):
+        self.v[:] = 0.0
+
     def close(self):
         pass

@@ -1,7 +1,7 @@
 """One rank of a multi-process SlabSolver test (launched by test_slab_cpu.py and
 test_gpu_slab.py with RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set).
 
-  python slab_worker.py <backend: numpy|hip|hip-rccl> <M> <Nv> <Ndown> <Nup> <omega> <tail_m> <pure_jacobi> [coarsest] [exact_coarse]
+  python slab_worker.py <backend: numpy|hip|hip-rccl> <M> <Nv> <Ndown> <Nup> <omega> <tail_m> <pure_jacobi> [coarsest] [exact_coarse] [fmg]
 
 Every rank builds the same global problem, solves it with the slab driver over
 gloo and compares the gathered solution and the residual history with the CPU
@@ -23,6 +23,7 @@ def main():
                                                    int(sys.argv[8]))
     coarsest = int(sys.argv[9]) if len(sys.argv) > 9 else 2
     exact = bool(int(sys.argv[10])) if len(sys.argv) > 10 else False
+    fmg = bool(int(sys.argv[11])) if len(sys.argv) > 11 else False  # full multigrid, Nv cycles per level
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -59,14 +60,17 @@ def main():
 
     S = slab.SlabSolver(M, dx, coarsest, backend=be, tail_m=tail_m, halo=8)
     S.set_problem(f, v0)
-    out = S.cycles(Nv, nd, nu, omega, pureJacobi=bool(pure))
+    out = S.fmg(Nv, nd, nu, omega) if fmg else S.cycles(Nv, nd, nu, omega, pureJacobi=bool(pure))
     sol = S.gather_solution()
     S.close()
 
     ok = True
     if rank == 0:
-        ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, coarsest, pure_jacobi=bool(pure),
-                                         coarse_exact=exact)
+        if fmg:
+            ref_sol, ref_rn = O.fmg(f, v0, dx, Nv, nd, nu, omega, coarsest, coarse_exact=exact)
+        else:
+            ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, coarsest, pure_jacobi=bool(pure),
+                                             coarse_exact=exact)
         if exact and backend != "numpy":
             # the GPU's sine-transform solve agrees with the oracle's Cholesky to rounding only
             same_rn = bool(np.allclose(out.ResidualNorms, ref_rn, rtol=1e-6, atol=1e-9 * ref_rn[0]))

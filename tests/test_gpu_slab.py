@@ -53,6 +53,21 @@ def test_ranks_share_gpu_exact_coarse_even_coarsest(O):
     assert "resnorms_equal=True sol_equal=True" in outs[0]
 
 
+@pytest.mark.parametrize("world,M,tail_m,ncyc", [(1, 513, 65, 1), (2, 513, 65, 1), (3, 1025, 129, 2), (2, 2049, 257, 1)])
+def test_full_multigrid_over_slabs(O, world, M, tail_m, ncyc):
+    """SlabSolver.fmg with the HIP backend (ranks share the GPU, gloo) against the oracle's composition."""
+    codes, outs = run_ranks(world, ["hip", M, ncyc, 2, 2, 0.6, tail_m, 0, 2, 0, 1], timeout=400)
+    assert codes == [0] * world, "\n".join(outs)
+    assert "resnorms_equal=True sol_equal=True" in outs[0]
+
+
+def test_rccl_group_of_one_rank_full_multigrid(O):
+    codes, outs = run_ranks(1, ["hip-rccl", 1025, 1, 2, 2, 0.6, 129, 0, 2, 0, 1], timeout=400,
+                            extra_env={"MGX_COMM_FORCE": "1"})
+    assert codes == [0], "\n".join(outs)
+    assert "resnorms_equal=True sol_equal=True" in outs[0]
+
+
 def test_rccl_group_of_one_rank(O):
     """The RCCL calls of the multi-GPU path (process group bound to the device, all-gather
     into the tail plan's own buffer, max-reduction of the norm slots) on the one GPU there

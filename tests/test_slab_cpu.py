@@ -113,6 +113,16 @@ def test_gloo_ranks_other_hierarchies(O, world, M, tail_m, exact):
     assert "resnorms_equal=True sol_equal=True" in outs[0]
 
 
+@pytest.mark.parametrize("world,M,tail_m,ncyc,nd,nu", [(1, 129, 33, 1, 2, 2), (2, 129, 33, 1, 2, 2), (2, 257, 33, 2, 2, 2),
+                                                       (3, 257, 33, 1, 1, 2), (2, 257, 65, 1, 3, 3), (4, 513, 65, 1, 2, 2),
+                                                       (2, 129, 17, 1, 4, 0)])
+def test_full_multigrid_over_slabs_matches_oracle(O, world, M, tail_m, ncyc, nd, nu):
+    """SlabSolver.fmg (an extension) against the same composition of the oracle's operators."""
+    codes, outs = run_ranks(world, ["numpy", M, ncyc, nd, nu, 0.6, tail_m, 0, 2, 0, 1])
+    assert codes == [0] * world, "\n".join(outs)
+    assert "resnorms_equal=True sol_equal=True" in outs[0]
+
+
 def test_ownership_is_nested_and_covers_every_level(O):
     from multigrid_amd import slab
 
