@@ -354,7 +354,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
 #define MGX_LOCKSTEP 32
 #endif
 #if MGX_LOCKSTEP > 0
-        // Keep the workgroup's four strips within MGX_LOCKSTEP columns of each
+        // Keep the workgroup's strips within MGX_LOCKSTEP columns of each
         // other, so that the halo rows two of them share are still in the XCD's
         // L2 when the second wave reads them (measured: -2.4 % on the level-0
         // launch).  All waves of a workgroup march the same chunk, hence the same
@@ -376,10 +376,10 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
 }
 
 template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
-__global__ __launch_bounds__(256) void k_stream(const StreamArgs A)
+__global__ __launch_bounds__(512) void k_stream(const StreamArgs A)
 {
     using G = Geo<NS, PA, NM, RES>;
-    const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strip = blockIdx.x * A.nwv + (threadIdx.x >> 6);  // A.nwv strips (waves) per workgroup
     if (strip >= A.nstrips) return;
     const int r0 = strip * G::S - G::PADLO;
     const bool edge = (r0 < 1) || (r0 + 127 > A.m - 2);
@@ -387,6 +387,76 @@ __global__ __launch_bounds__(256) void k_stream(const StreamArgs A)
         stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, true>(A, strip, (int)blockIdx.y);
     else
         stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, false>(A, strip, (int)blockIdx.y);
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Shape of one launch: strips (waves) per workgroup, columns per chunk, LDS to reserve.
+struct LaunchShape {
+    int nwv = 4, CJ = 256;
+    size_t lds = 0;
+};
+
+// Plain shape.  Chunk length: long enough to amortise the pipeline warm-up on a large
+// level (256 columns: 4 % of re-read), short enough that a small level still spreads
+// over the chip (down to 4 columns: a small level is latency-bound, so a shorter march
+// beats less redundant work).
+LaunchShape plain_shape(int nstrips, int ncolsout)
+{
+    static const int cj_max = env_int("MGX_CJ", 256), cj_min = env_int("MGX_CJ_MIN", 4);
+    static const int min_blocks = env_int("MGX_MIN_BLOCKS", 1024);
+    LaunchShape sh;
+    const int nsg = (nstrips + sh.nwv - 1) / sh.nwv;
+    sh.CJ = cj_max;
+    while (sh.CJ > cj_min && (long)nsg * ((ncolsout + sh.CJ - 1) / sh.CJ) < min_blocks) sh.CJ >>= 1;
+    return sh;
+}
+
+// Shape for a big launch that streams BOTH the iterate and the right-hand side (the
+// level-0 launches).  Two measured effects, 16385^2 V(2,2) up+down launch, 1.73 ms plain:
+//  * few resident waves: reserving 64 KB of (unused) LDS per workgroup leaves two
+//    workgroups per CU instead of six, and eight strips per workgroup instead of four
+//    share more halo rows inside a workgroup (1.73 -> 1.62 -> 1.56 ms);
+//  * whole rounds: capped workgroups run in rounds of 2 x #CUs, and a last round that is
+//    nearly empty wastes the chip, so the number of chunks is made a whole number of
+//    rounds (rounded down), at least three, with chunks of about 192 columns.
+// Launches that read only f (levels >= 1) and launches too small for chunks of 64
+// columns lose from the cap and keep the plain shape.  Defaults are the measured optimum
+// at 8193^2..32769^2; the environment variables exist for re-tuning.
+bool capped_shape(int nstrips, int ncolsout, LaunchShape &sh)
+{
+    static const int cap_lds = env_int("MGX_CAP_LDS", 65536), cap_cj = env_int("MGX_CAP_CJ", 192);
+    static const int cap_rounds = env_int("MGX_CAP_ROUNDS", 3), cap_wgs = env_int("MGX_CAP_WGS", 2);
+    static const int cap_minblk = env_int("MGX_CAP_MINBLK", 512);
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    if (cap_lds <= 0 || cap_lds > 65536) return false;
+    const long slots = (long)cap_wgs * ncu;
+    for (int nwv = 8; nwv >= 4; nwv >>= 1) {  // eight strips per workgroup if the chunks stay long
+        const long nsg = (nstrips + nwv - 1) / nwv;
+        const long want = nsg * ((ncolsout + cap_cj - 1) / cap_cj);
+        long rounds = (want + slots / 2) / slots;
+        if (rounds < cap_rounds) rounds = cap_rounds;
+        const long nch = rounds * slots / nsg;
+        if (nch < 1 || nsg * nch < cap_minblk) continue;
+        int cj = (int)((ncolsout + nch - 1) / nch);
+        cj += cj & 1;
+        if (cj < (nwv == 8 ? 128 : 64)) continue;
+        sh.nwv = nwv;
+        sh.CJ = cj;
+        sh.lds = (size_t)cap_lds;
+        return true;
+    }
+    return false;
 }
 
 template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
@@ -397,22 +467,14 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
     A.nstrips = (m - 1 + G::S - 1) / G::S;  // strips own rows 0..m-2
     const int ncolsout = A.jhi - A.jlo;
     if (ncolsout <= 0 || m < 3) return hipSuccess;
-    // chunk length: long enough to amortise the pipeline warm-up on the large
-    // levels (256 columns: 3 % of re-read), short enough that a small level
-    // still spreads over the chip (down to 4 columns: a small level is
-    // latency-bound, so a shorter march beats less redundant work).  The
-    // defaults are the measured optimum at 16385^2 V(2,2); the environment
-    // variables exist for re-tuning.
-    static const int cj_max = [] { const char *e = getenv("MGX_CJ"); return e ? atoi(e) : 256; }();
-    static const int cj_min = [] { const char *e = getenv("MGX_CJ_MIN"); return e ? atoi(e) : 4; }();
-    static const int min_blocks = [] { const char *e = getenv("MGX_MIN_BLOCKS"); return e ? atoi(e) : 1024; }();
-    int CJ = cj_max;
-    const int nsg = (A.nstrips + 3) / 4;
-    while (CJ > cj_min && (long)nsg * ((ncolsout + CJ - 1) / CJ) < min_blocks) CJ >>= 1;
-    A.CJ = CJ;
-    A.nchunks = (ncolsout + CJ - 1) / CJ;
+    LaunchShape sh = plain_shape(A.nstrips, ncolsout);
+    if (!ZERO_IN) capped_shape(A.nstrips, ncolsout, sh);
+    A.CJ = sh.CJ;
+    A.nwv = sh.nwv;
+    A.nchunks = (ncolsout + sh.CJ - 1) / sh.CJ;
+    const int nsg = (A.nstrips + sh.nwv - 1) / sh.nwv;
     hipLaunchKernelGGL((k_stream<NS, PA, NM, RES, ZERO_IN, STORE>), dim3((unsigned)nsg, (unsigned)A.nchunks),
-                       dim3(256), 0, s, A);
+                       dim3(64 * (unsigned)sh.nwv), sh.lds, s, A);
     return hipGetLastError();
 }
 
