@@ -65,7 +65,7 @@ def fused_bytes_per_point(kernel, nd, nu):
 # HBM bytes per launch from the PMC counters (rocprofv3 --pmc, separate passes, gfx950
 # corrections applied) for the default workload; measured in its own run, kept with the
 # round's profiles.  None for any other configuration.
-PMC_TRAFFIC = {("k_stream:updown", 16385, 2, 2): (8.171e9, "profiles/r01_final_pmc_traffic.txt")}
+PMC_TRAFFIC = {("k_stream:updown", 16385, 2, 2): (8.094e9, "profiles/r01_final_pmc_traffic.txt")}
 
 
 def rocprof_kernel_name(kernel, nd, nu):

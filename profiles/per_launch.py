@@ -4,7 +4,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
     if "mgx" not in n:
         continue
-    g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) // 256
+    g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_X"]))
     by[(n.replace("void mgx::(anonymous namespace)::", "").replace("(mgx::StreamArgs)", "")[:40], g)].append(
         int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = 0

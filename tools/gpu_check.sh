@@ -1,8 +1,10 @@
 set -e
 mkdir -p gpurun_out
-b() { python3 -c "import json; d=json.load(open('gpurun_out/occ.json')); print('$1', round(d['ms_per_step'],4), round(d['roofline']['avg_launch_ms'],4))"; }
-for size in 32769 16385 8193 4097 2049; do
-timeout -k 10 120 python bench.py --size $size --steps 50 --cpu-baseline off > gpurun_out/occ.json; b "$size default"
-done
-timeout -k 10 120 python bench.py --steps 50 --cpu-baseline off --slab > gpurun_out/occ.json; b "16385 slab"
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread 2>&1 | grep -v "Direct solver" | tail -4
+export TMPDIR=/tmp
+R=$PWD
+rm -rf gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/kt
+timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_f -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > gpurun_out/pmc_f.log 2>&1
+timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_w -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > gpurun_out/pmc_w.log 2>&1
+timeout -s KILL 180 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt -o kt --output-format csv -- python3 bench.py --steps 20 --warmup 3 --cpu-baseline off > gpurun_out/kt.log 2>&1
+timeout -k 10 300 python bench.py > gpurun_out/bench_default.json
+tail -c 400 gpurun_out/bench_default.json
