@@ -61,7 +61,7 @@ def test_fmg_with_exact_coarsest_solve(mg, O):
 
 
 def test_fmg_plus_vcycles_at_32769_schedules_agree(mg):
-    """BASELINE config 5 (FMG + V-cycles on 32769^2): far too big for the CPU oracle in
+    """FMG + V-cycles on 32769^2 (the largest benchmark configuration): far too big for the CPU oracle in
     seconds, so the two independent GPU schedules must agree bit for bit, FMG must start the
     finest level well below the zero-guess residual, and the V-cycles after it must contract."""
     import torch

@@ -144,7 +144,7 @@ def test_device_resident_api_and_repeated_calls(mg, O, sched):
 
 @pytest.mark.parametrize("sched", SCHEDS)
 def test_large_4097_against_oracle(mg, O, sched):
-    """BASELINE config 2 (4097^2, V(2,2)), 2 cycles: the oracle needs a few seconds."""
+    """4097^2, V(2,2) (the single-GPU validation size), 2 cycles: the oracle needs a few seconds."""
     from multigrid_amd import rhs
     m = 4097
     dx = 1.0 / (m - 1)
@@ -157,7 +157,7 @@ def test_large_4097_against_oracle(mg, O, sched):
 
 
 def test_schedules_agree_at_16385(mg):
-    """BASELINE config 3 size: too big for the oracle in seconds, so the two
+    """The benchmark size 16385^2: too big for the oracle in seconds, so the two
     independent GPU schedules (one kernel per operator vs fused) must agree
     bit for bit, and the residual history must contract."""
     import torch

@@ -1,10 +1,11 @@
 set -e
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-R=$PWD
-rm -rf gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/kt
-timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_f -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > gpurun_out/pmc_f.log 2>&1
-timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_w -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > gpurun_out/pmc_w.log 2>&1
-timeout -s KILL 180 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt -o kt --output-format csv -- python3 bench.py --steps 20 --warmup 3 --cpu-baseline off > gpurun_out/kt.log 2>&1
-timeout -k 10 300 python bench.py > gpurun_out/bench_default.json
-tail -c 400 gpurun_out/bench_default.json
+b() { python3 -c "import json; d=json.load(open('gpurun_out/occ.json')); print('$1', round(d['ms_per_step'],4), round(d['roofline']['avg_launch_ms'],4))"; }
+timeout -k 10 120 python bench.py --steps 50 --cpu-baseline off > gpurun_out/occ.json; b "default"
+for cfg in "8 60" "8 30" "2 60" "2 30" "1 60"; do
+set -- $cfg
+MGX_EXP_NWV=$1 MGX_EXP_MINSTRIPS=$2 timeout -k 10 120 python bench.py --steps 50 --cpu-baseline off > gpurun_out/occ.json; b "plain nwv $1 minstrips $2"
+done
+for mb in 512 2048; do
+MGX_MIN_BLOCKS=$mb timeout -k 10 120 python bench.py --steps 50 --cpu-baseline off > gpurun_out/occ.json; b "min_blocks $mb"
+done
