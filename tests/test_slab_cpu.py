@@ -94,6 +94,14 @@ def test_gloo_ranks_match_oracle(O, world, M, tail_m):
     assert "resnorms_equal=True sol_equal=True" in outs[0]
 
 
+def test_eight_ranks(O):
+    """The rank count of a full node: V-cycles and full multigrid."""
+    for args in (["numpy", 1025, 2, 2, 2, 0.6, 129, 0], ["numpy", 1025, 1, 2, 2, 0.6, 129, 0, 2, 0, 1]):
+        codes, outs = run_ranks(8, args, timeout=600)
+        assert codes == [0] * 8, "\n".join(outs)
+        assert "ndist=3 resnorms_equal=True sol_equal=True" in outs[0]
+
+
 def test_gloo_other_sweep_counts_and_pure_jacobi(O):
     for args in (["numpy", 129, 2, 5, 6, 0.8, 33, 0], ["numpy", 129, 2, 0, 2, 0.6, 33, 0],
                  ["numpy", 129, 3, 2, 2, 0.6, 33, 1], ["numpy", 129, 3, 1, 2, 0.7, 17, 0],
