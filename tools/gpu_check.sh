@@ -1,11 +1,7 @@
 set -e
 mkdir -p gpurun_out
-b() { python3 -c "import json; d=json.load(open('gpurun_out/occ.json')); print('$1', round(d['ms_per_step'],4), round(d['roofline']['avg_launch_ms'],4))"; }
-timeout -k 10 120 python bench.py --steps 50 --cpu-baseline off > gpurun_out/occ.json; b "default"
-for cfg in "8 60" "8 30" "2 60" "2 30" "1 60"; do
-set -- $cfg
-MGX_EXP_NWV=$1 MGX_EXP_MINSTRIPS=$2 timeout -k 10 120 python bench.py --steps 50 --cpu-baseline off > gpurun_out/occ.json; b "plain nwv $1 minstrips $2"
+for n in 2 4; do
+MGX_DIST_BACKEND=gloo timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2950$n bench.py --gpus $n --steps 5 --warmup 1 > gpurun_out/rehearse_$n.json 2> gpurun_out/rehearse_$n.err
+python3 -c "import json; d=json.loads(open('gpurun_out/rehearse_$n.json').read().strip().splitlines()[-1]); print($n, round(d['ms_per_step'],3), d['config']['decomposition'], d['resnorm_first_last'], d['roofline']['kernel'][-40:], round(d['roofline']['points_per_launch']))"
 done
-for mb in 512 2048; do
-MGX_MIN_BLOCKS=$mb timeout -k 10 120 python bench.py --steps 50 --cpu-baseline off > gpurun_out/occ.json; b "min_blocks $mb"
-done
+timeout -k 10 100 python bench.py --steps 5 --warmup 1 --cpu-baseline off | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(1, d['resnorm_first_last'])"
