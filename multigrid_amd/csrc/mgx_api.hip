@@ -313,13 +313,27 @@ int launch_leg(mgx_plan *p, int d, int kid, const StreamOp &op, const StreamArgs
     return MGX_OK;
 }
 
-// down leg of level d: relax(Ndown) + residual + coarsen (main.cpp:321-327)
-int fused_down(mgx_plan *p, int d, const FusedCtx &cx)
+// down leg of level d: relax(Ndown) + residual + coarsen (main.cpp:321-327); with norm0
+// (level 0, first cycle of a call, Ndown <= STREAM_MAX_SWEEPS) the same pass also yields the
+// norm of the residual of the iterate it starts from (main.cpp:307)
+int fused_down(mgx_plan *p, int d, const FusedCtx &cx, unsigned long long *norm0 = nullptr)
 {
     Level &L = p->lv[d];
     Level &C = p->lv[d + 1];
     StreamArgs A = level_args(L, &C, cx.omega);
     A.cout = C.f;
+    if (norm0) {
+        StreamOp op;
+        op.ns = cx.Ndown;
+        op.nm = 0;
+        op.res = 1;
+        op.store = cx.Ndown > 0 ? 1 : 0;
+        A.slot = norm0;
+        A.uin = L.v[L.cur];
+        A.uout = L.v[L.cur ^ 1];
+        if (op.store) L.cur ^= 1;
+        return launch_leg(p, d, MGX_KERNEL_FUSED_DOWN, op, A);
+    }
     if (cx.zero_start(d)) {
         if (cx.lean()) {  // nothing stored: the up leg recomputes these sweeps
             StreamOp op;
@@ -719,8 +733,13 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
     Level &L0 = p->lv[0];
     const SweepCoef c0 = make_coef(L0.dx, omega);
     HIP_TRY(hipMemsetAsync(p->slots, 0, sizeof(unsigned long long) * (size_t)(Nv + 1), s));
-    // main.cpp:307
-    if (p->schedule == MGX_SCHEDULE_FUSED) {  // the streaming kernel's 16-byte loads: 0.79 vs 1.09 ms at 16385^2
+    // main.cpp:307.  When the first cycle opens with a fused level-0 down leg, that launch
+    // takes the norm of the initial residual along (one pass over v and f saved per call).
+    const bool norm0_in_down = p->schedule == MGX_SCHEDULE_FUSED && !pure_jacobi && p->depth > 0 && Nv > 0 &&
+                               Ndown <= STREAM_MAX_SWEEPS;
+    if (norm0_in_down) {
+        // nothing here
+    } else if (p->schedule == MGX_SCHEDULE_FUSED) {  // the streaming kernel's 16-byte loads: 0.79 vs 1.09 ms at 16385^2
         StreamArgs A = level_args(L0, nullptr, omega);
         A.slot = p->slots + 0;
         rc = stream_chain(p, 0, MGX_KERNEL_RESNORM, s, 0, 0, 2, 0, A, L0.v, L0.cur);
@@ -738,7 +757,7 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
                 // lean: the previous cycle's level-0 launch already did this cycle's down leg
                 const bool lean = cx.lean() && (Ndown + Nup) >= 1;
                 rc = MGX_OK;
-                if (iter == 0 || !lean) rc = fused_down(p, 0, cx);
+                if (iter == 0 || !lean) rc = fused_down(p, 0, cx, (iter == 0 && norm0_in_down) ? p->slots + 0 : nullptr);
                 if (!rc) rc = fused_coarse_legs(p, cx);
                 if (!rc) rc = fused_up(p, 0, cx, slot, lean && iter + 1 < Nv);
                 norm_done = true;

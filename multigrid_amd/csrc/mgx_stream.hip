@@ -503,6 +503,10 @@ hipError_t launch_stream(const StreamOp &op, const StreamArgs &A, hipStream_t s)
     MGX_DOWN(0, false, false)
     MGX_FOR_NS1(MGX_DOWN, true, true)
     MGX_FOR_NS0(MGX_DOWN, true, false)
+    // the first down leg of a call together with the norm of the initial residual (main.cpp:307)
+    MGX_TRY(0, -1, 0, 1, false, false)
+    MGX_TRY(1, -1, 0, 1, false, true) MGX_TRY(2, -1, 0, 1, false, true)
+    MGX_TRY(3, -1, 0, 1, false, true) MGX_TRY(4, -1, 0, 1, false, true)
     // sweeps only (links of a chain longer than 4 sweeps)
 #define MGX_SWEEP(NS, Z) MGX_TRY(NS, -1, -1, 0, Z, true)
     MGX_FOR_NS1(MGX_SWEEP, false)
