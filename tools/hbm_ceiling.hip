@@ -4,7 +4,9 @@
 // 256 MiB Infinity Cache.  The V-cycle kernels are compared against these
 // numbers as well as against the 8 TB/s datasheet peak.
 //
-//   hipcc --offload-arch=gfx950 -O3 tools/hbm_ceiling.hip -o tools/hbm_ceiling && tools/hbm_ceiling [MiB]
+//   hipcc --offload-arch=gfx950 -O3 tools/hbm_ceiling.hip -o tools/hbm_ceiling && tools/hbm_ceiling [MiB] [LDS bytes]
+// The optional second argument reserves that much (unused) LDS per workgroup, which caps the
+// number of resident workgroups per CU: fewer concurrent streams can use the DRAM better.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void k_2r1w(const double2 *__restrict__ a, con
 int main(int argc, char **argv)
 {
     const size_t mib = argc > 1 ? (size_t)atol(argv[1]) : 2048;
+    const size_t lds = argc > 2 ? (size_t)atol(argv[2]) : 0;
     const size_t bytes = mib << 20;
     const size_t n = bytes / sizeof(double2);
     double2 *a, *b, *c;
@@ -68,8 +71,8 @@ int main(int argc, char **argv)
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     const int reps = 10;
-    const int grids[] = {2048, 4096, 8192, 16384, 65536};
-    printf("array %zu MiB, %d reps, best grid per kernel\n", mib, reps);
+    const int grids[] = {512, 1024, 1536, 2048, 4096, 8192, 16384, 65536};
+    printf("array %zu MiB, %d reps, %zu bytes of LDS reserved per workgroup, best grid per kernel\n", mib, reps, lds);
     for (int which = 0; which < 4; which++) {
         double best = 0;
         int bestg = 0;
@@ -77,10 +80,10 @@ int main(int argc, char **argv)
             for (int r = -2; r < reps; r++) {
                 if (r == 0) CHECK(hipEventRecord(e0, 0));
                 switch (which) {
-                case 0: hipLaunchKernelGGL(k_read, dim3(g), dim3(256), 0, 0, a, n, sink); break;
-                case 1: hipLaunchKernelGGL(k_write, dim3(g), dim3(256), 0, 0, b, n, 1.0); break;
-                case 2: hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, 0, a, b, n); break;
-                default: hipLaunchKernelGGL(k_2r1w, dim3(g), dim3(256), 0, 0, a, c, b, n); break;
+                case 0: hipLaunchKernelGGL(k_read, dim3(g), dim3(256), lds, 0, a, n, sink); break;
+                case 1: hipLaunchKernelGGL(k_write, dim3(g), dim3(256), lds, 0, b, n, 1.0); break;
+                case 2: hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), lds, 0, a, b, n); break;
+                default: hipLaunchKernelGGL(k_2r1w, dim3(g), dim3(256), lds, 0, a, c, b, n); break;
                 }
             }
             CHECK(hipEventRecord(e1, 0));
