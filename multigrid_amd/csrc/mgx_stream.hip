@@ -49,6 +49,11 @@
 // (mgx_kernels.hip), so both schedules produce identical bits.
 #include "mgx_internal.h"
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -417,7 +422,7 @@ int cu_count()
     return ncu;
 }
 
-LaunchShape plain_shape(int nstrips, int ncolsout)
+LaunchShape plain_shape(int nstrips, int ncolsout, int min_per_cu = 0, int min_cj = 0)
 {
     static const int cj_max = env_int("MGX_CJ", 256), cj_min = env_int("MGX_CJ_MIN", 4);
     static const int min_blocks = env_int("MGX_MIN_BLOCKS", 1024);
@@ -433,12 +438,16 @@ LaunchShape plain_shape(int nstrips, int ncolsout)
     if (bal_cj > 0) {
         const long ncu = cu_count();
         const long want = (long)nsg * ((ncolsout + bal_cj - 1) / bal_cj);
-        if (want >= 2 * ncu) {
-            const long q = (want + ncu / 2) / ncu;
+        long q = (want + ncu / 2) / ncu;
+        if (want >= 2 * ncu || (min_per_cu > 0 && q < min_per_cu)) {
+            // (with min_per_cu also a smaller launch: that many workgroups per CU, if the
+            // chunks then keep min_cj columns)
+            if (q < min_per_cu) q = min_per_cu;
             const long nch = q * ncu / nsg;
             if (nch >= 1) {
                 int cj = (int)((ncolsout + nch - 1) / nch);
-                sh.CJ = cj + (cj & 1);
+                cj += cj & 1;
+                if (want >= 2 * ncu || cj >= min_cj) sh.CJ = cj;
             }
         }
     }
@@ -482,6 +491,55 @@ bool capped_shape(int nstrips, int ncolsout, LaunchShape &sh)
     return false;
 }
 
+// Which shape is fastest for a big launch that streams both arrays depends on more than
+// its size (a full 16385^2 level gains 8 % from the cap, a tall slab of the same level or a
+// full 8193^2 level loses 5 %), so it is MEASURED where it runs.  The first launches of a
+// given geometry run the candidate shapes in turn, WINDOW consecutive launches each, every
+// launch between two events on the launch stream, and the shape with the smallest total is
+// kept.  Every shape computes the same bits, so the choice affects time only.  The
+// last launch of a window waits for its completion (the host would otherwise run far
+// ahead of the GPU and never see a result): one stream synchronisation per candidate, once
+// per geometry and process; after that nothing blocks.  MGX_TUNE=0 turns this off
+// (square-ish launches of at least 12000 columns then take the cap, others the plain shape).
+struct ShapeTuner {
+    static constexpr int MAXC = 3, WINDOW = 3;
+    struct Entry {
+        int device = -1, m = 0, ncols = 0;
+        int ncand = 0;
+        LaunchShape cand[MAXC];
+        float time[MAXC] = {0, 0, 0};
+        int chosen = -1, cur = 0, count = -1;  // count -1: one untimed launch first (cold start)
+        hipEvent_t e0[WINDOW] = {nullptr}, e1[WINDOW] = {nullptr};
+    };
+    std::mutex mu;
+    std::vector<Entry> entries;
+    Entry &find(int device, int m, int ncols)
+    {
+        for (Entry &e : entries)
+            if (e.device == device && e.m == m && e.ncols == ncols) return e;
+        entries.emplace_back();
+        Entry &e = entries.back();
+        e.device = device;
+        e.m = m;
+        e.ncols = ncols;
+        return e;
+    }
+};
+
+bool same_shape(const LaunchShape &a, const LaunchShape &b) { return a.nwv == b.nwv && a.CJ == b.CJ && a.lds == b.lds; }
+
+template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
+hipError_t launch_shape(StreamArgs A, const LaunchShape &sh, int ncolsout, hipStream_t s)
+{
+    A.CJ = sh.CJ;
+    A.nwv = sh.nwv;
+    A.nchunks = (ncolsout + sh.CJ - 1) / sh.CJ;
+    const int nsg = (A.nstrips + sh.nwv - 1) / sh.nwv;
+    hipLaunchKernelGGL((k_stream<NS, PA, NM, RES, ZERO_IN, STORE>), dim3((unsigned)nsg, (unsigned)A.nchunks),
+                       dim3(64 * (unsigned)sh.nwv), sh.lds, s, A);
+    return hipGetLastError();
+}
+
 template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
 hipError_t launch_one(StreamArgs A, hipStream_t s)
 {
@@ -490,15 +548,75 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
     A.nstrips = (m - 1 + G::S - 1) / G::S;  // strips own rows 0..m-2
     const int ncolsout = A.jhi - A.jlo;
     if (ncolsout <= 0 || m < 3) return hipSuccess;
-    LaunchShape sh = plain_shape(A.nstrips, ncolsout);
-    if (!ZERO_IN) capped_shape(A.nstrips, ncolsout, sh);
-    A.CJ = sh.CJ;
-    A.nwv = sh.nwv;
-    A.nchunks = (ncolsout + sh.CJ - 1) / sh.CJ;
-    const int nsg = (A.nstrips + sh.nwv - 1) / sh.nwv;
-    hipLaunchKernelGGL((k_stream<NS, PA, NM, RES, ZERO_IN, STORE>), dim3((unsigned)nsg, (unsigned)A.nchunks),
-                       dim3(64 * (unsigned)sh.nwv), sh.lds, s, A);
-    return hipGetLastError();
+    const LaunchShape plain = plain_shape(A.nstrips, ncolsout);
+    // candidates: the static guess first (it is the fallback), then the others
+    LaunchShape cands[ShapeTuner::MAXC];
+    int ncands = 0;
+    cands[ncands++] = plain;
+    if (!ZERO_IN && (long)m * ncolsout >= (8L << 20)) {
+        LaunchShape capped = plain;
+        if (capped_shape(A.nstrips, ncolsout, capped)) {
+            cands[ncands++] = capped;
+            if (4L * ncolsout >= 3L * m && ncolsout >= 12000) std::swap(cands[0], cands[1]);  // a big square level
+        }
+        const LaunchShape wide = plain_shape(A.nstrips, ncolsout, 3, 60);
+        if (!same_shape(wide, plain)) cands[ncands++] = wide;
+    }
+    static const int tune = env_int("MGX_TUNE", 1);
+    if (ncands == 1 || !tune) return launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, cands[0], ncolsout, s);
+
+    static ShapeTuner tuner;  // one per kernel instance
+    std::lock_guard<std::mutex> lock(tuner.mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    ShapeTuner::Entry &e = tuner.find(dev, m, ncolsout);
+    if (e.ncand == 0) {
+        for (int k = 0; k < ncands; k++) e.cand[e.ncand++] = cands[k];
+        for (int w = 0; w < ShapeTuner::WINDOW; w++)
+            if (hipEventCreate(&e.e0[w]) != hipSuccess || hipEventCreate(&e.e1[w]) != hipSuccess) e.chosen = 0;
+    }
+    if (e.chosen >= 0) return launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[e.chosen], ncolsout, s);
+    if (e.count < 0) {
+        e.count = 0;
+        return launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[0], ncolsout, s);
+    }
+    // (an event record fails e.g. on a stream under capture: tuning is then given up)
+    bool ok = hipEventRecord(e.e0[e.count], s) == hipSuccess;
+    const hipError_t rc = ok ? launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[e.cur], ncolsout, s)
+                             : launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[0], ncolsout, s);
+    ok = ok && rc == hipSuccess && hipEventRecord(e.e1[e.count], s) == hipSuccess;
+    if (ok && ++e.count == ShapeTuner::WINDOW) {
+        float ms = 0.f;
+        ok = hipEventSynchronize(e.e1[ShapeTuner::WINDOW - 1]) == hipSuccess;
+        for (int w = 0; ok && w < ShapeTuner::WINDOW; w++) {
+            float t = 0.f;
+            ok = hipEventElapsedTime(&t, e.e0[w], e.e1[w]) == hipSuccess;
+            ms += t;
+        }
+        if (ok) {
+            e.time[e.cur] = ms;
+            e.count = 0;
+            if (++e.cur == e.ncand) {
+                e.chosen = 0;
+                for (int k = 1; k < e.ncand; k++)
+                    if (e.time[k] < e.time[e.chosen]) e.chosen = k;
+                static const int verbose = env_int("MGX_TUNE_VERBOSE", 0);
+                if (verbose) {
+                    fprintf(stderr, "mgx tune k_stream<%d,%d,%d,%d,%d,%d> m=%d ncols=%d:", NS, PA, NM, RES, (int)ZERO_IN,
+                            (int)STORE, m, ncolsout);
+                    for (int k = 0; k < e.ncand; k++)
+                        fprintf(stderr, " [%d strips x %d cols, lds %zu: %.1f us / %d launches]%s", e.cand[k].nwv,
+                                e.cand[k].CJ, e.cand[k].lds, 1e3 * e.time[k], ShapeTuner::WINDOW, k == e.chosen ? "*" : "");
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        e.chosen = 0;
+    }
+    return rc;
 }
 
 } // namespace
