@@ -295,6 +295,15 @@ double mgx_norm_decode(unsigned long long slot);
  * (main.cpp:295-299,345); its Dirichlet boundary must then be zero too. */
 int mgx_plan_vcycle_async(mgx_plan *plan, int Ndown, int Nup, double omega, int zero_guess);
 
+/* Launch-shape tuning.  A fused launch over at least 8 M grid points that streams both the
+ * iterate and the right-hand side can run in two or three workgroup shapes that compute
+ * the same bits at different speeds.  The first nine launches of such a geometry in a
+ * process time the candidates in place (three launches each between events on the launch
+ * stream) and the third of each group waits for the stream; after that the fastest shape is
+ * used and the "async" entry points above never block.  The environment variable
+ * MGX_TUNE=0 turns the measurement off (a fixed rule picks the shape), MGX_TUNE_VERBOSE=1
+ * reports each decision on stderr. */
+
 #ifdef __cplusplus
 }
 #endif
