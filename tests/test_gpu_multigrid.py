@@ -215,3 +215,25 @@ def test_plan_on_a_stream_of_the_callers(mg, O, sched):
     assert_bits(out.ResidualNorms, rn, "ResNorms")
     assert_bits(mg.to_numpy(got), sol, "Sol")
     plan.close()
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_non_finite_right_hand_side(mg, O, sched, bad):
+    """calcNorm ignores NaNs (DTDoubleArray.cpp:883-899,923-939 compare with `<` and `>`) and
+    the residual array's zero boundary always takes part, so a run that drowns in NaNs
+    reports norm 0, not NaN; infinities win the comparison.  The GPU must follow suit."""
+    from multigrid_amd import rhs
+    m = 65
+    dx = 1.0 / (m - 1)
+    f = rhs.random_np(m)
+    f[20, 31] = bad
+    v0 = np.zeros((m, m), order="F")
+    sol, rn, _ = O.multigrid(f, v0, dx, 3, 2, 2, 0.6, 2)
+    v = v0.copy(order="F")
+    out = mg.solve_host(f, v, dx, 3, 2, 2, 0.6, 2, schedule=sched)
+    assert_bits(out.ResidualNorms, rn, "ResNorms")
+    # NaN payloads are not part of the contract: same NaN positions, same bits elsewhere
+    assert np.array_equal(np.isnan(v), np.isnan(sol))
+    ok = ~np.isnan(sol)
+    assert np.array_equal(v[ok].view(np.uint64), sol[ok].view(np.uint64))
