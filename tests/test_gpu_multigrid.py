@@ -224,16 +224,16 @@ def test_non_finite_right_hand_side(mg, O, sched, bad):
     the residual array's zero boundary always takes part, so a run that drowns in NaNs
     reports norm 0, not NaN; infinities win the comparison.  The GPU must follow suit."""
     from multigrid_amd import rhs
-    m = 65
-    dx = 1.0 / (m - 1)
-    f = rhs.random_np(m)
-    f[20, 31] = bad
-    v0 = np.zeros((m, m), order="F")
-    sol, rn, _ = O.multigrid(f, v0, dx, 3, 2, 2, 0.6, 2)
-    v = v0.copy(order="F")
-    out = mg.solve_host(f, v, dx, 3, 2, 2, 0.6, 2, schedule=sched)
-    assert_bits(out.ResidualNorms, rn, "ResNorms")
-    # NaN payloads are not part of the contract: same NaN positions, same bits elsewhere
-    assert np.array_equal(np.isnan(v), np.isnan(sol))
-    ok = ~np.isnan(sol)
-    assert np.array_equal(v[ok].view(np.uint64), sol[ok].view(np.uint64))
+    for m, Nv in ((65, 3), (257, 1), (513, 2)):
+        dx = 1.0 / (m - 1)
+        f = rhs.random_np(m)
+        f[20, 31] = bad
+        v0 = np.zeros((m, m), order="F")
+        sol, rn, _ = O.multigrid(f, v0, dx, Nv, 2, 2, 0.6, 2)
+        v = v0.copy(order="F")
+        out = mg.solve_host(f, v, dx, Nv, 2, 2, 0.6, 2, schedule=sched)
+        assert_bits(out.ResidualNorms, rn, "ResNorms m=%d" % m)
+        # NaN payloads are not part of the contract: same NaN positions, same bits elsewhere
+        assert np.array_equal(np.isnan(v), np.isnan(sol))
+        ok = ~np.isnan(sol)
+        assert np.array_equal(v[ok].view(np.uint64), sol[ok].view(np.uint64))
