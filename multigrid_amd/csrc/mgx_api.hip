@@ -203,6 +203,16 @@ int coarsest_solve(mgx_plan *p)
     return MGX_OK;
 }
 
+// main.cpp:341 adds an array with a +0.0 boundary to the fine iterate: its Dirichlet values
+// stay as they are, except that -0.0 turns into +0.0.  Both ping-pong buffers carry them.
+int normalize_boundary(mgx_plan *p)
+{
+    Level &L = p->lv[0];
+    HIP_TRY(launch_boundary_plus_zero(L.v[0], L.m, p->stream));
+    HIP_TRY(launch_boundary_plus_zero(L.v[1], L.m, p->stream));
+    return MGX_OK;
+}
+
 // One V(Ndown,Nup) cycle, one kernel per reference operator:
 // the body of the loop at main.cpp:317-346.
 int vcycle_stepwise(mgx_plan *p, int Ndown, int Nup, double omega)
@@ -230,7 +240,9 @@ int vcycle_stepwise(mgx_plan *p, int Ndown, int Nup, double omega)
         Level &L = p->lv[d];
         Level &C = p->lv[d + 1];
         LAUNCH(p, d, MGX_KERNEL_PROLONG_ADD, launch_refine(C.v[C.cur], C.m, L.v[L.cur], L.m, 1, L.m - 1, 0, 0, 1, s));
-        int rc = level_relax(p, d, Nup, omega);
+        int rc = d == 0 ? normalize_boundary(p) : MGX_OK;
+        if (rc) return rc;
+        rc = level_relax(p, d, Nup, omega);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(C.v[C.cur], 0, sizeof(double) * C.n(), s));  // main.cpp:345
     }
@@ -475,6 +487,7 @@ int vcycle_fused(mgx_plan *p, int Ndown, int Nup, double omega, unsigned long lo
     if (p->depth == 0) return coarsest_solve(p);
     int rc = fused_down(p, 0, cx);
     if (!rc) rc = fused_coarse_legs(p, cx);
+    if (!rc && !zero0) rc = normalize_boundary(p);
     if (!rc) rc = fused_up(p, 0, cx, (zero0 && cx.lean() && Ndown > 0) ? nullptr : norm_slot, false);
     return rc;
 }
@@ -759,6 +772,7 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
                 rc = MGX_OK;
                 if (iter == 0 || !lean) rc = fused_down(p, 0, cx, (iter == 0 && norm0_in_down) ? p->slots + 0 : nullptr);
                 if (!rc) rc = fused_coarse_legs(p, cx);
+                if (!rc && iter == 0) rc = normalize_boundary(p);  // later cycles find it done
                 if (!rc) rc = fused_up(p, 0, cx, slot, lean && iter + 1 < Nv);
                 norm_done = true;
             } else if (!pure_jacobi) {

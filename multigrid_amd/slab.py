@@ -630,7 +630,7 @@ class SlabSolver:
             self.be.take_rows(self.tail_gathered, self.tail_rows, out=t)
 
     # ---- the general schedule: a chain per leg, an exchange after every launch ----------
-    def _cycle_general(self, Ndown, Nup, omega, slot):
+    def _cycle_general(self, Ndown, Nup, omega, slot, first=False):
         nd = self.ndist
         for l in range(nd):  # main.cpp:317-328
             Lv = self.levels[l]
@@ -651,6 +651,8 @@ class SlabSolver:
             if items:
                 self.comm.exchange(items)
         vt = self._tail(Ndown, Nup, omega)
+        if first:
+            self._normalize_boundary()
         for l in range(nd - 1, -1, -1):  # main.cpp:335-346
             Lv = self.levels[l]
             C, cshape = self._coarse_of(l)
@@ -707,6 +709,19 @@ class SlabSolver:
             self._launch(l, "k_stream:up", op)
         return vt
 
+    def _normalize_boundary(self):
+        """main.cpp:341 adds an array whose boundary is +0.0 to the fine iterate: Dirichlet values
+        stay, except that -0.0 becomes +0.0.  The launches write interior points only, so the
+        boundary rows (and the physical boundary columns this rank holds) get it here."""
+        L0 = self.levels[0]
+        for v in L0.v:
+            v[:, 0] += 0.0
+            v[:, L0.m - 1] += 0.0
+            if L0.jfix_lo >= 0:
+                v[L0.jfix_lo, :] += 0.0
+            if L0.jfix_hi >= 0:
+                v[L0.jfix_hi, :] += 0.0
+
     def _lean_up0(self, Ndown, Nup, omega, vt, slot, next_down):
         """Level-0 up leg with the cycle's residual norm; with next_down also the down leg
         of the following cycle (one launch), then that cycle's exchange."""
@@ -756,9 +771,11 @@ class SlabSolver:
                 if it == 0:  # later cycles: the previous cycle's level-0 launch did the down leg
                     self._lean_down0(Ndown, omega)
                 vt = self._lean_coarse(Ndown, Nup, omega)
+                if it == 0:
+                    self._normalize_boundary()
                 self._lean_up0(Ndown, Nup, omega, vt, slot, next_down=it + 1 < Nv)
             else:
-                self._cycle_general(Ndown, Nup, omega, slot)
+                self._cycle_general(Ndown, Nup, omega, slot, first=it == 0)
             times[it + 1] = times[it] + (time.perf_counter() - t0)
         self.comm.allreduce_max_(slots)
         be.synchronize()

@@ -57,6 +57,7 @@ def main():
     v0 = np.zeros((M, M), order="F")
     v0[0, :], v0[-1, :], v0[:, 0], v0[:, -1] = rng.standard_normal((4, M))   # non-zero Dirichlet data
     v0[1:-1, 1:-1] = rng.standard_normal((M - 2, M - 2)) * 0.01              # and a non-zero guess
+    v0[0, 3] = v0[5, 0] = v0[-1, -1] = v0[-1, 7] = v0[M // 2, -1] = -0.0     # main.cpp:341 turns these into +0.0
 
     S = slab.SlabSolver(M, dx, coarsest, backend=be, tail_m=tail_m, halo=8)
     S.set_problem(f, v0)

@@ -64,6 +64,7 @@ def test_solver_matches_oracle_random_rhs(mg, O, m, Nv, nd, nu, omega, sched):
     # non-zero Dirichlet data and a non-zero interior guess: the API takes both
     v0[0, :], v0[-1, :], v0[:, 0], v0[:, -1] = rng.standard_normal((4, m))
     v0[1:-1, 1:-1] = rng.standard_normal((m - 2, m - 2)) * 0.01
+    v0[0, 1] = v0[2, 0] = v0[-1, -1] = v0[-1, 1] = v0[1, -1] = -0.0  # main.cpp:341 turns these into +0.0
     sol, rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, 2)
     v = v0.copy(order="F")
     out = mg.solve_host(f, v, dx, Nv, nd, nu, omega, 2, schedule=sched)
@@ -237,3 +238,21 @@ def test_non_finite_right_hand_side(mg, O, sched, bad):
         assert np.array_equal(np.isnan(v), np.isnan(sol))
         ok = ~np.isnan(sol)
         assert np.array_equal(v[ok].view(np.uint64), sol[ok].view(np.uint64))
+
+
+@pytest.mark.parametrize("sched", SCHEDS)
+def test_negative_zero_boundary_values(mg, O, sched):
+    """`cur += refined` (main.cpp:341) runs over the whole array, boundary included, and the
+    boundary of `refined` is +0.0: a Dirichlet value of -0.0 becomes +0.0 in the first cycle --
+    but not with zero cycles and not in pureJacobi mode, which never get there."""
+    m = 33
+    rng = np.random.default_rng(4)
+    f = np.asfortranarray(rng.standard_normal((m, m)))
+    v0 = np.asfortranarray(rng.standard_normal((m, m)) * 0.0)  # a mix of +0.0 and -0.0 everywhere
+    assert np.signbit(v0[0, :]).any() and np.signbit(v0[:, -1]).any()
+    for Nv, nd, nu, pj in ((2, 2, 2, False), (1, 5, 3, False), (0, 2, 2, False), (2, 2, 2, True), (1, 0, 0, False)):
+        sol, rn, _ = O.multigrid(f, v0, 1.0 / (m - 1), Nv, nd, nu, 0.7, 2, pure_jacobi=pj)
+        v = v0.copy(order="F")
+        out = mg.solve_host(f, v, 1.0 / (m - 1), Nv, nd, nu, 0.7, 2, pureJacobi=pj, schedule=sched)
+        assert_bits(out.ResidualNorms, rn, "ResNorms %r" % ((Nv, nd, nu, pj),))
+        assert_bits(v, sol, "Sol %r" % ((Nv, nd, nu, pj),))
