@@ -368,8 +368,11 @@ class SlabSolver:
         R = self.comm.size
         self.W0 = max(halo, SlabSolver.W0)
         # levels 0..nd-1 are distributed, level nd is the top of the tail
+        # (the tail is a plan of its own and a plan's finest level is odd: an even coarsest
+        # level cannot be the whole tail)
+        max_nd = self.depth - (1 if dims[-1] % 2 == 0 else 0)
         nd = 0
-        while nd < self.depth and dims[nd] > tail_m:
+        while nd < max_nd and dims[nd] > tail_m:
             # would every rank still own at least a halo's worth of columns of every
             # level if one more level were distributed?
             Ev, Ef = view_capacity(nd + 1)

@@ -67,6 +67,25 @@ def test_numpy_backend_single_slab_matches_oracle(O):
         assert_bits(sol, ref_sol, "Sol V(%d,%d)" % (nd, nu))
 
 
+def test_even_coarsest_level_is_never_the_whole_tail(O):
+    """Levels 37, 19, 10: the tail is a hierarchy of its own and its finest level must be odd, so
+    with tail_m below 19 the tail still starts at 19."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from slab_numpy_backend import NumpyBackend
+    from multigrid_amd import rhs, slab
+    M = 37
+    f = rhs.random_np(M)
+    v0 = np.zeros((M, M), order="F")
+    S = slab.SlabSolver(M, 1.0 / (M - 1), 9, backend=NumpyBackend(O), tail_m=11)
+    assert S.dims == [37, 19, 10] and S.ndist == 1
+    S.set_problem(f, v0)
+    out = S.cycles(2, 2, 2, 0.6)
+    ref_sol, ref_rn, _ = O.multigrid(f, v0, 1.0 / (M - 1), 2, 2, 2, 0.6, 9)
+    assert_bits(out.ResidualNorms, ref_rn, "ResNorms")
+    assert_bits(S.gather_solution(), ref_sol, "Sol")
+    S.close()
+
+
 def test_lean_schedule_exchanges_once_per_cycle(O):
     """With Ndown+Nup <= 4 a cycle costs ONE neighbour exchange (level-0 iterate + level-1
     right-hand side); the coarser distributed levels recompute their halo columns."""

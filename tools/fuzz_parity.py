@@ -26,6 +26,47 @@ while time.time() < t_end:
     f = np.asfortranarray(rng.standard_normal((M, M)))
     v0 = np.asfortranarray(rng.standard_normal((M, M)) * float(rng.choice([0.0, 1.0])))
     dx = float(rng.choice([1.0, 1.0 / (M - 1), 0.37]))
+    mode = int(rng.integers(0, 10))
+    if mode == 0 and not pj:  # full multigrid
+        try:
+            sol, rn = O.fmg(f, v0, dx, Nv, nd, nu, omega, coarsest)
+        except ValueError:
+            continue
+        prob = mg.gridtype(mg.to_device(f), mg.to_device(v0), dx)
+        out = mg.FullMultiGrid(prob, Nv, nd, nu, omega, coarsest, schedule=sched)
+        v = mg.to_numpy(prob.v)
+        n += 1
+        if not (np.array_equal(out.ResidualNorms.view(np.uint64), rn.view(np.uint64)) and
+                np.array_equal(v.view(np.uint64), sol.view(np.uint64))):
+            print("FMG MISMATCH", dict(M=M, coarsest=coarsest, nd=nd, nu=nu, omega=omega, ncyc=Nv, sched=sched, dx=dx))
+            sys.exit(1)
+        continue
+    if mode == 1 and M >= 65:  # the slab driver on one rank, V-cycles or full multigrid
+        from multigrid_amd import slab
+        tail_m = int(rng.choice([17, 33, 65, 129]))
+        use_fmg = bool(rng.integers(0, 2)) and not pj
+        try:
+            if use_fmg:
+                sol, rn = O.fmg(f, v0, dx, Nv, nd, nu, omega, coarsest)
+            else:
+                sol, rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, coarsest, pure_jacobi=pj)
+        except ValueError:
+            continue
+        try:
+            S = slab.SlabSolver(M, dx, coarsest, schedule=sched, tail_m=tail_m)
+        except ValueError:
+            continue
+        S.set_problem(f, v0)
+        out = S.fmg(Nv, nd, nu, omega) if use_fmg else S.cycles(Nv, nd, nu, omega, pureJacobi=pj)
+        v = S.gather_solution()
+        S.close()
+        n += 1
+        if not (np.array_equal(out.ResidualNorms.view(np.uint64), rn.view(np.uint64)) and
+                np.array_equal(np.ascontiguousarray(v).view(np.uint64), np.ascontiguousarray(sol).view(np.uint64))):
+            print("SLAB MISMATCH", dict(M=M, coarsest=coarsest, nd=nd, nu=nu, omega=omega, Nv=Nv, sched=sched, pj=pj, dx=dx,
+                                        tail_m=tail_m, fmg=use_fmg, ndist=S.ndist))
+            sys.exit(1)
+        continue
     try:
         sol, rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, coarsest, pure_jacobi=pj)
     except ValueError:
