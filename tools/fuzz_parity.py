@@ -1,6 +1,6 @@
 """Randomised parity sweep (not part of the test suite): random hierarchy shapes, sweep
 counts, omega, schedules, boundary data and cycle counts against the CPU oracle, bit for bit.
-   python tools/fuzz_parity.py [seconds] [seed]"""
+   python tools/fuzz_parity.py [seconds] [seed] [largest size]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,13 +9,14 @@ from oracle import oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+MAXM = int(sys.argv[3]) if len(sys.argv) > 3 else 1800
 t_end = time.time() + budget
 n = 0
 while time.time() < t_end:
     k = int(rng.integers(1, 12))
-    d = int(rng.integers(1, 9))
+    d = int(rng.integers(1, 13 if MAXM > 2000 else 9))
     M = k * 2 ** d + 1
-    if M < 5 or M > 1800 or M % 2 == 0:
+    if M < 5 or M > MAXM or M % 2 == 0:
         continue
     coarsest = int(rng.choice([1, 2, 2, 2, 3, 4, 6, 11, k, 2 * k]))
     nd, nu = int(rng.integers(0, 8)), int(rng.integers(0, 8))
@@ -65,6 +66,25 @@ while time.time() < t_end:
                 np.array_equal(np.ascontiguousarray(v).view(np.uint64), np.ascontiguousarray(sol).view(np.uint64))):
             print("SLAB MISMATCH", dict(M=M, coarsest=coarsest, nd=nd, nu=nu, omega=omega, Nv=Nv, sched=sched, pj=pj, dx=dx,
                                         tail_m=tail_m, fmg=use_fmg, ndist=S.ndist))
+            sys.exit(1)
+        continue
+    if mode == 2 and not pj:  # the exact coarsest solve (an extension): agreement to rounding, not bitwise
+        try:
+            sol, rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, coarsest, coarse_exact=True)
+        except ValueError:
+            continue
+        v = v0.copy(order="F")
+        try:
+            out = mg.solve_host(f, v, dx, Nv, nd, nu, omega, coarsest, schedule=sched, coarse_solve=mg.COARSE_EXACT)
+        except mg.MgxError as e:
+            if "exact coarsest-grid solve takes at most" in str(e):
+                continue
+            raise
+        n += 1
+        scale = max(np.abs(sol).max(), 1e-300)
+        if not (np.abs(v - sol).max() <= 1e-8 * scale and np.allclose(out.ResidualNorms, rn, rtol=1e-5, atol=1e-8 * max(rn[0], 1e-300))):
+            print("EXACT-COARSE MISMATCH", dict(M=M, coarsest=coarsest, nd=nd, nu=nu, omega=omega, Nv=Nv, sched=sched, dx=dx),
+                  np.abs(v - sol).max() / scale, out.ResidualNorms.tolist(), rn.tolist())
             sys.exit(1)
         continue
     try:
