@@ -11,8 +11,12 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 MAXM = int(sys.argv[3]) if len(sys.argv) > 3 else 1800
 t_end = time.time() + budget
+t_say = time.time() + 30
 n = 0
 while time.time() < t_end:
+    if time.time() > t_say:
+        print("... %d cases so far" % n, flush=True)
+        t_say = time.time() + 30
     k = int(rng.integers(1, 12))
     d = int(rng.integers(1, 13 if MAXM > 2000 else 9))
     M = k * 2 ** d + 1
