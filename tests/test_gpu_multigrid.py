@@ -256,3 +256,22 @@ def test_negative_zero_boundary_values(mg, O, sched):
         out = mg.solve_host(f, v, 1.0 / (m - 1), Nv, nd, nu, 0.7, 2, pureJacobi=pj, schedule=sched)
         assert_bits(out.ResidualNorms, rn, "ResNorms %r" % ((Nv, nd, nu, pj),))
         assert_bits(v, sol, "Sol %r" % ((Nv, nd, nu, pj),))
+
+
+@pytest.mark.parametrize("k,d", [(5, 10), (3, 11), (7, 10), (9, 10), (11, 10), (3, 12), (7, 11), (13, 10)])
+def test_schedules_agree_at_large_sizes_that_are_not_powers_of_two(mg, k, d):
+    """Sizes k*2^d+1 between 5000 and 15000 (coarsest = k: the hierarchy ends on a (k+1)^2 grid):
+    the big level-0 launches run in their capped, tuned shapes with ragged last strips and
+    chunks; the one-kernel-per-operator schedule is the independent implementation to match."""
+    import torch
+    from multigrid_amd import rhs
+    m = k * 2 ** d + 1
+    dx = 1.0 / (m - 1)
+    f = rhs.random_torch(m)
+    res = []
+    for sched in (mg.SCHEDULE_STEPWISE, mg.SCHEDULE_FUSED):
+        prob = mg.gridtype(f, mg.colmajor(m, m), dx)
+        out = mg.MultiGrid(prob, 4, 2, 2, 0.6, k, schedule=sched)
+        res.append((out.ResidualNorms, prob.v))
+    assert_bits(res[0][0], res[1][0], "ResNorms m=%d" % m)
+    assert torch.equal(res[0][1].view(torch.int64), res[1][1].view(torch.int64))
