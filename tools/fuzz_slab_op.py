@@ -15,6 +15,7 @@ from slab_numpy_backend import NumpyBackend, _decode
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 hip, ref = slab.HipBackend(), NumpyBackend(O)
+BIG = os.environ.get("FUZZ_BIG") == "1"  # bigger slabs: interior strips, long chunks (slower emulation)
 t_end, t_say, n = time.time() + budget, time.time() + 30, 0
 # (nsweeps, pro_stage, norm_stage, restrict_out, zero_in, store): the legs the schedules compose
 def random_leg():
@@ -41,10 +42,10 @@ while time.time() < t_end:
         t_say = time.time() + 30
     ns, pa, nm, res, zin, st = random_leg()
     halo = ns + (2 if res else (1 if nm == ns and nm >= 0 else 0))
-    mc = int(rng.integers(3, 200))
+    mc = int(rng.integers(3, 1500 if BIG else 200))
     m = 2 * mc - 1
     left, right = bool(rng.integers(0, 3) == 0), bool(rng.integers(0, 3) == 0)
-    own = int(rng.integers(1, 60))
+    own = int(rng.integers(1, 700 if BIG else 60))
     extra_lo, extra_hi = int(rng.integers(0, 4)), int(rng.integers(0, 4))
     jlo = 1 if left else halo + extra_lo
     jhi = jlo + own
