@@ -119,7 +119,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="V-cycles timed (the reference's default Nv is 100)")
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=8,
+                    help="untimed cycles first (eight let the launch-shape measurement finish before the timed region)")
     ap.add_argument("--size", type=int, default=16385, help="grid points per side (2^k+1)")
     ap.add_argument("--nd", type=int, default=2)
     ap.add_argument("--nu", type=int, default=2)
