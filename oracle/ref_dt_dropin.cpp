@@ -18,7 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "mgx.h"
+#include "mgx_multigrid.hpp"
 
 // the two aggregates MultiGrid() trades in (main.cpp:29-40)
 struct gridtype {
@@ -32,19 +32,11 @@ struct MGOutputs {
     MGOutputs(DTDoubleArray r, DTDoubleArray t) : ResidualNorms(r), Times(t) {}
 };
 
-// Drop-in for main.cpp:283: same signature, same in-place solution, same two output vectors.
+// Drop-in for main.cpp:283: same signature, same in-place solution, same two output vectors;
+// the body is include/mgx_multigrid.hpp, the binding this repository ships.
 MGOutputs MultiGrid(gridtype &prob, int Nv, int Ndown, int Nup, double omega, int coarsest, bool pureJacobi = false)
 {
-    DTMutableDoubleArray v = prob.v.DoubleData();  // shares storage with prob.v (main.cpp:288)
-    DTMutableDoubleArray f = prob.f.DoubleData();
-    DTMutableDoubleArray resnorm(Nv + 1), times(Nv + 1);
-    const int rc = mgx_solve2d(f.Pointer(), v.Pointer(), (int)v.m(), (int)v.n(), prob.v.Grid().dx(), Nv, Ndown, Nup,
-                               omega, coarsest, pureJacobi ? 1 : 0, resnorm.Pointer(), times.Pointer(), NULL);
-    if (rc != MGX_OK) {
-        printf("Error: %s\n", mgx_last_error());
-        exit(1);
-    }
-    return MGOutputs(resnorm, times);
+    return mgx::MultiGrid<MGOutputs, DTMutableDoubleArray>(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi);
 }
 
 int main(int argc, char **argv)
