@@ -14,12 +14,18 @@
  * (-O2 -ffp-contract=off): the left-to-right expression trees below are the
  * definition of a correct result, bit for bit.
  *
- * Parity pin: the reference's main.cpp cannot be built in this image (it
- * includes boost/program_options.hpp, which is absent, and stand-ins are not
- * allowed), and the reference ships no tests or fixtures.  This restatement is
- * pinned by the known answers captured from the reference when it was surveyed
- * (tests/golden/reference_known_answers.json) and, for Maximum/Minimum/+=, by
- * the reference's own DTSource sources compiled into oracle/_ref.
+ * Parity pin: the reference's own solver functions (main.cpp:147-357, all of
+ * main.cpp except the boost include at :21-23 and main() at :360-459) are
+ * compiled from the reference checkout into oracle/_ref/librefops.so
+ * (oracle/Makefile, oracle/ref_main_harness.cpp; -O2 -DNDEBUG
+ * -ffp-contract=off).  tests/test_oracle.py compares every function below with
+ * it bit for bit on seeded inputs, and against that library's committed
+ * outputs (tests/golden/reference_vectors.npz, reference_known_answers.json)
+ * where the checkout is absent.  Maximum/Minimum/+= are additionally checked
+ * against the reference's DTSource sources (oracle/_ref/libdtref.so).
+ * Deviation: a hierarchy with a level of fewer than 3 points (coarsest = 1
+ * ends in a 2x2 grid with no unknowns, which the reference walks through) is
+ * refused here, as it is by the product.
  *
  * The same file builds a second library, libmg_oracle_omp.so (-fopenmp): the
  * loops over columns carry OpenMP pragmas.  Every grid point is computed by

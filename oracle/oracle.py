@@ -106,6 +106,104 @@ def ref_lib():
     return _REF
 
 
+_OPS = None
+
+
+def ref_ops():
+    """The reference's own solver functions (main.cpp:147-357) compiled from the reference
+    checkout into oracle/_ref/librefops.so (oracle/Makefile, oracle/ref_main_harness.cpp), or
+    None if not built.  Used only to pin this oracle."""
+    global _OPS
+    if _OPS is None:
+        path = os.path.join(_HERE, "_ref", "librefops.so")
+        if not os.path.exists(path):
+            return None
+        L = ctypes.CDLL(path)
+        i, d = ctypes.c_int, ctypes.c_double
+        L.ref_calc_norm.restype = d
+        L.ref_calc_norm.argtypes = [_dp, i]
+        L.ref_relax.restype = None
+        L.ref_relax.argtypes = [_dp, _dp, i, d, i, d]
+        L.ref_residual.restype = None
+        L.ref_residual.argtypes = [_dp, _dp, _dp, i, d]
+        L.ref_coarsen.restype = None
+        L.ref_coarsen.argtypes = [_dp, i, _dp, i]
+        L.ref_refine.restype = None
+        L.ref_refine.argtypes = [_dp, i, _dp, i]
+        L.ref_direct_solve.restype = None
+        L.ref_direct_solve.argtypes = [_dp, _dp, i, d]
+        L.ref_depth.restype = i
+        L.ref_depth.argtypes = [i, i]
+        L.ref_multigrid.restype = None
+        L.ref_multigrid.argtypes = [_dp, _dp, i, d, i, i, i, d, i, i, _dp, _dp]
+        _OPS = L
+    return _OPS
+
+
+class Ref:
+    """numpy front end of ref_ops() with the same call shapes as this module's functions, so a
+    test can run `O.relax(...)` and `O.Ref().relax(...)` side by side."""
+
+    def __init__(self):
+        self.L = ref_ops()
+        if self.L is None:
+            raise RuntimeError("oracle/_ref/librefops.so not built (reference checkout absent)")
+
+    def calc_norm(self, r):
+        r = _f64(r)
+        assert r.ndim == 2 and r.shape[0] == r.shape[1]
+        return self.L.ref_calc_norm(_ptr(r), r.shape[0])
+
+    def relax(self, u, f, dx, niter, omega):
+        u = _f64(u).copy(order="F")
+        f = _f64(f)
+        self.L.ref_relax(_ptr(u), _ptr(f), u.shape[0], dx, niter, omega)
+        return u
+
+    def residual(self, u, f, dx):
+        u = _f64(u)
+        f = _f64(f)
+        r = np.full(u.shape, np.nan, order="F")
+        self.L.ref_residual(_ptr(u), _ptr(f), _ptr(r), u.shape[0], dx)
+        return r
+
+    def coarsen(self, fine, mc=None):
+        fine = _f64(fine)
+        mf = fine.shape[0]
+        if mc is None:
+            mc = (mf - 1) // 2 + 1
+        c = np.full((mc, mc), np.nan, order="F")
+        self.L.ref_coarsen(_ptr(fine), mf, _ptr(c), mc)
+        return c
+
+    def refine(self, coarse, mf=None):
+        coarse = _f64(coarse)
+        mc = coarse.shape[0]
+        if mf is None:
+            mf = 2 * (mc - 1) + 1
+        fine = np.full((mf, mf), np.nan, order="F")
+        self.L.ref_refine(_ptr(coarse), mc, _ptr(fine), mf)
+        return fine
+
+    def direct_solve(self, u, f, dx):
+        u = _f64(u).copy(order="F")
+        f = _f64(f)
+        self.L.ref_direct_solve(_ptr(u), _ptr(f), u.shape[0], dx)
+        return u
+
+    def depth(self, m, coarsest):
+        return self.L.ref_depth(m, coarsest)
+
+    def multigrid(self, f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pure_jacobi=False):
+        f = _f64(f)
+        v = _f64(v).copy(order="F")
+        res = np.zeros(Nv + 1)
+        tim = np.zeros(Nv + 1)
+        self.L.ref_multigrid(_ptr(f), _ptr(v), f.shape[0], dx, Nv, Ndown, Nup, omega, coarsest,
+                             int(bool(pure_jacobi)), _ptr(res), _ptr(tim))
+        return v, res, tim
+
+
 def calc_norm(r):
     r = np.ascontiguousarray(np.asarray(r, dtype=np.float64).ravel(order="K"))
     return lib().mgo_calc_norm(_ptr(r), r.size)
@@ -127,10 +225,11 @@ def residual(u, f, dx):
     return r
 
 
-def coarsen(fine):
+def coarsen(fine, mc=None):
     fine = _f64(fine)
     mf = fine.shape[0]
-    mc = (mf - 1) // 2 + 1
+    if mc is None:
+        mc = (mf - 1) // 2 + 1
     c = np.empty((mc, mc), dtype=np.float64, order="F")
     lib().mgo_coarsen(_ptr(fine), mf, _ptr(c), mc)
     return c

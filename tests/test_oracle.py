@@ -256,3 +256,122 @@ def test_even_coarsest_level_is_a_legal_hierarchy(O):
     assert rn2[3] < 0.2 * rn[3]  # an exact coarsest solve converges much faster
     with pytest.raises(ValueError):
         O.multigrid(rhs.random_np(91), np.zeros((91, 91), order="F"), 1.0 / 90, 1, 2, 2, 0.6, 2)  # 91, 46, 23, ...
+
+
+# ---- against the reference's own solver functions -----------------------------
+# main.cpp:147-357 compiled from the reference checkout (oracle/_ref/librefops.so, recipe in
+# oracle/Makefile).  Two layers: the committed outputs of that library
+# (tests/golden/reference_vectors.npz, made by tests/golden/make_golden.py) are checked
+# everywhere; the library itself is called side by side with the oracle where it is built.
+
+@pytest.fixture(scope="module")
+def refvec():
+    import os
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, "reference_vectors.npz"))
+
+
+def _golden_cases():
+    import importlib.util
+    import os
+    from conftest import GOLDEN
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_MG = _golden_cases()
+
+
+@pytest.mark.parametrize("m", _MG.OP_SIZES)
+def test_reference_vectors_operators(O, refvec, m):
+    V, k, dx = refvec, "op%d_" % m, 1.0 / (m - 1)
+    u, f = V[k + "u"], V[k + "f"]
+    assert_bits(O.relax(u, f, dx, 1, 0.6), V[k + "relax1_w06"], "relax")
+    assert_bits(O.relax(u, f, dx, 3, 0.9), V[k + "relax3_w09"], "relax x3")
+    assert_bits(O.residual(u, f, dx), V[k + "residual"], "residual")
+    assert_bits(np.array([O.calc_norm(u)]), np.array([float(V[k + "norm"])]), "calcNorm")
+    assert_bits(O.direct_solve(u, f, dx)[0], V[k + "direct"], "direct_solve")
+    if m >= 5:
+        assert_bits(O.coarsen(u), V[k + "coarsen"], "coarsen")
+        assert_bits(O.refine(V[k + "c"], m), V[k + "refine"], "refine")
+
+
+@pytest.mark.parametrize("mf,mc", [(23, 12), (7, 4)])
+def test_reference_vectors_even_level_transfers(O, refvec, mf, mc):
+    V, k = refvec, "even%d_" % mf
+    assert_bits(O.coarsen(V[k + "fine"], mc), V[k + "coarsen"], "coarsen to an even level")
+    assert_bits(O.refine(V[k + "c"], mf), V[k + "refine"], "refine from an even level")
+
+
+@pytest.mark.parametrize("case", _MG.MG_CASES, ids=[c[0] for c in _MG.MG_CASES])
+def test_reference_vectors_multigrid(O, refvec, case):
+    name, m, Nv, nd, nu, om, co, pj, data = case
+    V = refvec
+    f, v = _MG.mg_inputs(name, m, data)
+    assert_bits(f, V[name + "_f"], "seeded f")   # the generator is part of the fixture
+    assert_bits(v, V[name + "_v"], "seeded v")
+    sol, rn, _ = O.multigrid(V[name + "_f"], V[name + "_v"], 1.0 / (m - 1), Nv, nd, nu, om, co, pure_jacobi=pj)
+    assert_bits(sol, V[name + "_sol"], "Sol")
+    assert_bits(rn, V[name + "_resnorms"], "ResNorms")
+    assert O.depth(m, co) == int(V[name + "_depth"])
+
+
+def test_reference_vectors_depth_table(O, refvec):
+    for m, c, d in refvec["depth_table"]:
+        assert O.depth(int(m), int(c)) == int(d), (m, c)
+
+
+def _R(O):
+    if O.ref_ops() is None:
+        pytest.skip("oracle/_ref/librefops.so not built (reference checkout absent)")
+    return O.Ref()
+
+
+def _rand(rng, m, scale=1.0):
+    return np.asfortranarray(rng.standard_normal((m, m)) * scale)
+
+
+@pytest.mark.parametrize("m", [3, 5, 9, 17, 33, 65, 129, 257, 513])
+def test_live_reference_operators(O, m):
+    R = _R(O)
+    rng = np.random.default_rng(1000 + m)
+    dx = 1.0 / (m - 1)
+    u, f = _rand(rng, m), _rand(rng, m, 100.0)
+    u[0, :] = -0.0
+    for (n, w) in [(1, 0.6), (2, 0.8), (4, 1.0)]:
+        assert_bits(O.relax(u, f, dx, n, w), R.relax(u, f, dx, n, w), "relax %d %.1f" % (n, w))
+    assert_bits(O.residual(u, f, dx), R.residual(u, f, dx), "residual")
+    assert_bits(np.array([O.calc_norm(u)]), np.array([R.calc_norm(u)]), "calcNorm")
+    assert_bits(O.direct_solve(u, f, dx)[0], R.direct_solve(u, f, dx), "direct_solve")
+    if m >= 5:
+        assert_bits(O.coarsen(u), R.coarsen(u), "coarsen")
+        c = _rand(rng, (m - 1) // 2 + 1)
+        assert_bits(O.refine(c, m), R.refine(c, m), "refine")
+        # cur += refined over the whole array (main.cpp:341): -0.0 boundary becomes +0.0
+        x = u.copy(order="F")
+        O.lib().mgo_plus_equals(x.ctypes.data_as(O._dp), O.refine(c, m).ctypes.data_as(O._dp), x.size)
+        assert not np.signbit(x[0, :]).any()
+
+
+@pytest.mark.parametrize("m,Nv,nd,nu,om,co,pj", [
+    (129, 4, 2, 2, 0.6, 2, False), (257, 3, 3, 3, 0.6, 2, False), (513, 2, 2, 2, 0.6, 2, False),
+    (257, 3, 1, 2, 0.9, 2, False), (129, 3, 5, 5, 0.7, 2, False), (129, 2, 0, 0, 0.6, 2, False),
+    (129, 3, 2, 2, 0.6, 4, False), (65, 3, 2, 2, 0.6, 8, False), (177, 3, 2, 2, 0.6, 11, False),
+    (97, 3, 2, 2, 0.6, 3, False), (193, 3, 2, 2, 0.6, 6, False), (257, 6, 2, 2, 0.6, 2, True),
+    (5, 3, 2, 2, 0.6, 2, False), (3, 3, 2, 2, 0.6, 2, False)])
+def test_live_reference_multigrid(O, m, Nv, nd, nu, om, co, pj):
+    R = _R(O)
+    rng = np.random.default_rng(7 * m + Nv + co)
+    f, v = _rand(rng, m, 50.0), _rand(rng, m)
+    if m % 2:
+        v[:, 0] = -0.0
+        v[-1, :] = -0.0
+    dx = 1.0 / (m - 1)
+    assert O.depth(m, co) == R.depth(m, co)
+    a = O.multigrid(f, v, dx, Nv, nd, nu, om, co, pure_jacobi=pj)
+    b = R.multigrid(f, v, dx, Nv, nd, nu, om, co, pj)
+    assert_bits(a[0], b[0], "Sol")
+    assert_bits(a[1], b[1], "ResNorms")
+    assert b[2][0] == 0 and np.all(np.diff(b[2]) >= 0)   # Times: cumulative (main.cpp:308,350)
