@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MGX_VERSION 100
+#define MGX_VERSION 200
 
 #define MGX_OK 0
 #define MGX_ERR_ARG (-1)      /* bad size / null pointer / non-square / even size   */
@@ -88,11 +88,18 @@ int mgx_depth(int m, int coarsest);
  *   dx                 : prob.v.Grid().dx()
  *   resnorms host, Nv+1: infinity norm of the fine residual before the first
  *                        cycle and after each cycle (main.cpp:307,351-353)
- *   times    host, Nv+1: times[0]=0; times[k] = cumulative seconds of device
- *                        time spent in cycles 1..k.  (The reference sums
- *                        wall time around relax() only, main.cpp:320-322,
- *                        342-344,350; with fused kernels smoothing is not
- *                        separable, so whole-cycle device time is reported.)
+ *   times    host, Nv+1: times[0]=0 (main.cpp:308); times[k] = times[k-1] +
+ *                        seconds of cycle k.  The reference sums wall time
+ *                        around its relax() calls only (main.cpp:320-322,
+ *                        342-344,350).  MGX_SCHEDULE_STEPWISE reports the same
+ *                        quantity as device time: HIP events around the
+ *                        launches of every relax() of the cycle (0 for
+ *                        pure_jacobi, as in the reference).  The fused
+ *                        schedules (the default) cannot separate smoothing
+ *                        from the transfers it is fused with and report
+ *                        whole-cycle device time instead; with the level-0
+ *                        up+down fusion the event that closes cycle k also
+ *                        covers the level-0 down leg of cycle k+1.
  * Stopping rule: exactly Nv cycles, no tolerance test (main.cpp:309).
  * ------------------------------------------------------------------------ */
 int mgx_solve2d(const double *f, double *v, int m, int n, double dx,
@@ -141,6 +148,10 @@ int mgx_plan_download(mgx_plan *plan, double *v_host);
  * does; NULL only skips the copy to the host. */
 int mgx_plan_cycles(mgx_plan *plan, int Nv, int Ndown, int Nup, double omega, int pure_jacobi,
                     double *resnorms, double *times);
+
+/* The stream the plan's work is enqueued on from now on (options.stream at creation).  Work
+ * already enqueued on the previous stream is ordered before anything that follows. */
+int mgx_plan_set_stream(mgx_plan *plan, void *stream);
 
 /* EXTENSION (the reference has no full-multigrid driver): nested iteration with the
  * reference's own operators.  The right-hand side is restricted to every level
@@ -297,12 +308,27 @@ int mgx_plan_vcycle_async(mgx_plan *plan, int Ndown, int Nup, double omega, int 
 
 /* Launch-shape tuning.  A fused launch over at least 8 M grid points that streams both the
  * iterate and the right-hand side can run in two or three workgroup shapes that compute
- * the same bits at different speeds.  The first nine launches of such a geometry in a
- * process time the candidates in place (three launches each between events on the launch
- * stream) and the third of each group waits for the stream; after that the fastest shape is
- * used and the "async" entry points above never block.  The environment variable
- * MGX_TUNE=0 turns the measurement off (a fixed rule picks the shape), MGX_TUNE_VERBOSE=1
- * reports each decision on stderr. */
+ * the same bits at different speeds; which one is fastest is measured once per geometry and
+ * process.  No counterpart in the reference.
+ *   mgx_plan_tune()   measures now, for every level-0 launch a run of V(Ndown,Nup) cycles on
+ *                     this plan issues: three cycles with each candidate shape run on the spot
+ *                     (blocking), then the fine iterate is put back as it was.  Call it after
+ *                     the data is set and before the cycles that matter; later calls of
+ *                     mgx_plan_cycles() never block for tuning.
+ *   mgx_tune_mode(1)  the same forced measurement for whatever the calling thread launches
+ *                     (mgx_slab_launch, mgx_plan_vcycle_async) until mgx_tune_mode(0); returns
+ *                     the previous setting.  A launch repeats safely: it never writes what it
+ *                     reads and merges norms by a max.
+ * Without either, the first ten launches of such a geometry time the candidates in place
+ * (three launches each between events on the launch stream; the third of each group waits
+ * for the stream).  Environment: MGX_TUNE=0 turns measuring off (a fixed rule picks the
+ * shape), MGX_TUNE_VERBOSE=1 reports each decision on stderr. */
+int mgx_plan_tune(mgx_plan *plan, int Ndown, int Nup, double omega);
+int mgx_tune_mode(int enable);
+/* Forget every measured shape of this process: the next launches measure again (tests use
+ * it to send every candidate shape through a parity check).  Not to be called while another
+ * thread launches. */
+int mgx_tune_reset(void);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,10 @@ struct mgx_plan {
     size_t evused = 0;
     double prof_ms[MGX_KERNEL_COUNT] = {0};
     long prof_n[MGX_KERNEL_COUNT] = {0};
+    // stepwise schedule: event pairs around every relax() of a cycle (Times as main.cpp:320-322,342-344)
+    struct RelaxRec { int cycle; hipEvent_t a, b; };
+    std::vector<RelaxRec> relax_recs;
+    int relax_cycle = -1;  // >= 0 while mgx_plan_cycles() wants relax() bracketed
 };
 
 namespace {
@@ -187,6 +191,22 @@ int level_relax(mgx_plan *p, int d, int niter, double omega)
     return MGX_OK;
 }
 
+// relax() as the V-cycle loop calls it (main.cpp:320-322, 342-344): inside mgx_plan_cycles()
+// the launches are bracketed by an event pair, the device-time counterpart of the
+// reference's timer.Start()/Stop() around relax only.
+int timed_relax(mgx_plan *p, int d, int niter, double omega)
+{
+    if (p->relax_cycle < 0 || niter <= 0) return level_relax(p, d, niter, omega);
+    hipEvent_t a = prof_event(p), b = prof_event(p);
+    if (!a || !b) return level_relax(p, d, niter, omega);
+    HIP_TRY(hipEventRecord(a, p->stream));
+    int rc = level_relax(p, d, niter, omega);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(b, p->stream));
+    p->relax_recs.push_back({p->relax_cycle, a, b});
+    return MGX_OK;
+}
+
 // main.cpp:331: the coarsest grid.  3x3: the reference's closed form; any other size:
 // nothing (the reference prints a message, main.cpp:167), or with MGX_COARSE_EXACT the
 // exact solve (an extension).
@@ -222,7 +242,7 @@ int vcycle_stepwise(mgx_plan *p, int Ndown, int Nup, double omega)
     for (int d = 0; d < depth; d++) {  // main.cpp:317-328
         Level &L = p->lv[d];
         Level &C = p->lv[d + 1];
-        int rc = level_relax(p, d, Ndown, omega);
+        int rc = timed_relax(p, d, Ndown, omega);
         if (rc) return rc;
         const SweepCoef c = make_coef(L.dx, omega);
         // residual(): boundary columns 0 and m-1 are zero, the kernel fills the rest
@@ -242,7 +262,7 @@ int vcycle_stepwise(mgx_plan *p, int Ndown, int Nup, double omega)
         LAUNCH(p, d, MGX_KERNEL_PROLONG_ADD, launch_refine(C.v[C.cur], C.m, L.v[L.cur], L.m, 1, L.m - 1, 0, 0, 1, s));
         int rc = d == 0 ? normalize_boundary(p) : MGX_OK;
         if (rc) return rc;
-        rc = level_relax(p, d, Nup, omega);
+        rc = timed_relax(p, d, Nup, omega);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(C.v[C.cur], 0, sizeof(double) * C.n(), s));  // main.cpp:345
     }
@@ -784,11 +804,13 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
                 norm_done = true;
             }
         } else if (!pure_jacobi) {
+            p->relax_cycle = times ? iter : -1;
             rc = vcycle_stepwise(p, Ndown, Nup, omega);
+            p->relax_cycle = -1;
         } else {
-            rc = level_relax(p, 0, 1, omega);  // main.cpp:348
+            rc = level_relax(p, 0, 1, omega);  // main.cpp:348 (not timed there either)
         }
-        if (rc) return rc;
+        if (rc) { p->relax_recs.clear(); return rc; }
         // main.cpp:351-353
         if (!norm_done)
             LAUNCH(p, 0, MGX_KERNEL_RESNORM, launch_residual_norm(L0.v[L0.cur], L0.f, L0.m, 1, L0.m - 1, c0, slot, s));
@@ -799,6 +821,16 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
         L0.cur = 0;
     }
     HIP_TRY(hipStreamSynchronize(s));
+    std::vector<double> relax_s;  // stepwise: seconds inside relax() per cycle
+    if (times && p->schedule == MGX_SCHEDULE_STEPWISE) {
+        relax_s.assign((size_t)Nv, 0.0);
+        for (const mgx_plan::RelaxRec &r : p->relax_recs) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+            relax_s[(size_t)r.cycle] += 1e-3 * (double)ms;
+        }
+    }
+    p->relax_recs.clear();
     rc = prof_collect(p);
     if (rc) return rc;
     if (resnorms) {
@@ -809,11 +841,65 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
     if (times) {
         times[0] = 0;  // main.cpp:308
         for (int k = 1; k <= Nv; k++) {
+            if (p->schedule == MGX_SCHEDULE_STEPWISE) {  // main.cpp:350: time inside relax() only
+                times[k] = times[k - 1] + relax_s[(size_t)k - 1];
+                continue;
+            }
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, p->events[k - 1], p->events[k]));
-            times[k] = times[k - 1] + 1e-3 * (double)ms;  // main.cpp:350 (whole-cycle device time)
+            times[k] = times[k - 1] + 1e-3 * (double)ms;  // fused: smoothing is not separable, whole-cycle device time
         }
     }
+    return MGX_OK;
+}
+
+int mgx_tune_mode(int enable) { return set_tune_now(enable != 0) ? 1 : 0; }
+
+int mgx_tune_reset(void)
+{
+    tune_forget();
+    return MGX_OK;
+}
+
+int mgx_plan_tune(mgx_plan *p, int Ndown, int Nup, double omega)
+{
+    DeviceScope on_plan_device(p);
+    if (!p) return fail(MGX_ERR_ARG, "mgx_plan_tune: null plan");
+    if (Ndown < 0 || Nup < 0) return fail(MGX_ERR_ARG, "mgx_plan_tune: negative count");
+    if (p->schedule != MGX_SCHEDULE_FUSED || p->depth == 0) return MGX_OK;  // nothing to choose
+    Level &L0 = p->lv[0];
+    const size_t nb = sizeof(double) * L0.n();
+    // three cycles visit every level-0 launch of a run (first down leg, up+down, last up leg)
+    // with the measurement forced; the iterate is put back afterwards (p->r is idle in this
+    // schedule), coarse levels are rebuilt by every cycle anyway
+    HIP_TRY(hipMemcpyAsync(p->r, L0.v[0], nb, hipMemcpyDeviceToDevice, p->stream));
+    const bool was = set_tune_now(true);
+    const int prof = p->profile;
+    p->profile = 0;
+    const int rc = mgx_plan_cycles(p, 3, Ndown, Nup, omega, 0, nullptr, nullptr);
+    p->profile = prof;
+    set_tune_now(was);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(L0.v[0], p->r, nb, hipMemcpyDeviceToDevice, p->stream));
+    const int rc2 = mgx_plan_commit(p);
+    if (rc2) return rc2;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MGX_OK;
+}
+
+int mgx_plan_set_stream(mgx_plan *p, void *stream)
+{
+    DeviceScope on_plan_device(p);
+    if (!p) return fail(MGX_ERR_ARG, "mgx_plan_set_stream: null plan");
+    if ((hipStream_t)stream == p->stream) return MGX_OK;
+    // work already enqueued on the old stream must be visible to the new one
+    if (p->events.empty()) {
+        int rc = ensure_events(p, 1);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(p->events[0], p->stream));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->events[0], 0));
+    p->stream = (hipStream_t)stream;
     return MGX_OK;
 }
 
@@ -865,10 +951,12 @@ int mgx_plan_fmg(mgx_plan *p, int ncyc, int Ndown, int Nup, double omega, double
         view.slots = p->slots;
         view.nslots = p->nslots;
         view.events.swap(p->events);
+        view.evpool.swap(p->evpool);
         const bool top = l == 0;
         const int rc = mgx_plan_cycles(&view, ncyc, Ndown, Nup, omega, 0, top ? resnorms : nullptr,
                                        top ? times : nullptr);
         p->events.swap(view.events);
+        p->evpool.swap(view.evpool);
         p->slots = view.slots;
         p->nslots = view.nslots;
         for (int k = l; k <= depth; k++) p->lv[k] = view.lv[k - l];  // buffers may have traded places

@@ -110,6 +110,12 @@ struct StreamOp {
     int ns = 0, pa = -1, nm = -1, res = 0, zero_in = 0, store = 1;
 };
 hipError_t launch_stream(const StreamOp &op, const StreamArgs &A, hipStream_t s);
+// While set (per host thread), a launch whose geometry has no measured shape yet runs every
+// candidate shape on the spot (one untimed + three timed launches each, one stream
+// synchronisation per candidate) and keeps the fastest.  Returns the previous setting.
+bool set_tune_now(bool on);
+// Forget every measured launch shape of this process (the next launches measure again).
+void tune_forget();
 // halo columns (and rows) the pipeline of `op` consumes beyond the produced range
 int stream_halo(const StreamOp &op);
 // The four-flag form of the simple legs: pro in {0,1}; res 0 none, 1 restrict,

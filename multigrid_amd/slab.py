@@ -149,9 +149,15 @@ class _HipTail:
         self.f = _device_view(be.L.mgx_plan_f_dev(self.h), m, be.device)
         self.v = _device_view(be.L.mgx_plan_v_dev(self.h), m, be.device)
 
+    def _on_current_stream(self):
+        # the all-gather and the index copy that fill self.f, and the up leg that reads
+        # self.v, run on torch's current stream: so must the plan
+        _lib.check(self.be.L.mgx_plan_set_stream(self.h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
     def run(self, Ndown, Nup, omega):
         """One V(Ndown,Nup) cycle from a zero guess for the right-hand side in self.f;
         returns the iterate (self.v).  Asynchronous on the current stream."""
+        self._on_current_stream()
         _lib.check(self.be.L.mgx_plan_vcycle_async(self.h, Ndown, Nup, omega, 1))
         return self.v
 
@@ -160,6 +166,7 @@ class _HipTail:
         boundary values in self.v; returns the result (the plan's iterate buffer may have
         traded places with its twin, so the view is taken again)."""
         L = self.be.L
+        self._on_current_stream()
         _lib.check(L.mgx_plan_commit(self.h))
         _lib.check(L.mgx_plan_fmg(self.h, ncyc, Ndown, Nup, omega, None, None))
         self.v = _device_view(L.mgx_plan_v_dev(self.h), self.m, self.be.device)
@@ -167,6 +174,7 @@ class _HipTail:
 
     def reset(self):
         """Zero iterate with zero boundary values: what a cycle's coarse-grid correction starts from."""
+        self._on_current_stream()
         self.v.zero_()
         _lib.check(self.be.L.mgx_plan_commit(self.h))
 
@@ -475,6 +483,24 @@ class SlabSolver:
             a, b = self.bounds[0][k], self.bounds[0][k + 1]
             out[:, a:b] = allc[k * width:k * width + (b - a)].T
         return out
+
+    def tune(self, Ndown, Nup, omega):
+        """Measure the launch shapes of this rank's big launches now (mgx_tune_mode) by running
+        three cycles whose level-0 iterate is put back afterwards.  Collective: every rank calls it."""
+        if self.be.name != "hip":
+            return
+        L0 = self.levels[0]
+        keep = L0.v[L0.cur].clone()
+        L = self.be.L
+        was = L.mgx_tune_mode(1)
+        try:
+            self.cycles(3, Ndown, Nup, omega)
+        finally:
+            L.mgx_tune_mode(was)
+        L0.v[0].copy_(keep)
+        L0.v[1].copy_(keep)
+        L0.cur = 0
+        self.be.synchronize()
 
     # ---- profiling hooks (same surface as solver.Plan) -----------------------------
     def profile(self, enable=True):

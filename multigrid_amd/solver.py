@@ -230,6 +230,11 @@ class Plan:
         except Exception:
             pass
 
+    def _on_current_stream(self):
+        """The plan runs on whatever torch stream is current at each call (work it enqueued
+        on the stream of an earlier call is ordered first)."""
+        _lib.check(self._L.mgx_plan_set_stream(self._h, _stream_ptr()))
+
     @property
     def depth(self):
         return self._L.mgx_plan_depth(self._h)
@@ -247,6 +252,7 @@ class Plan:
         for t, name in ((f, "f"), (v, "v")):
             if _square_odd(t, name) != m:
                 raise ValueError("%s does not match the plan size %d" % (name, m))
+        self._on_current_stream()
         _lib.check(self._L.mgx_plan_set_dev(self._h, f.data_ptr(), v.data_ptr()))
 
     def get(self, out=None):
@@ -256,8 +262,15 @@ class Plan:
             out = colmajor(m, m, "cuda", zero=False)
         elif _square_odd(out, "out") != m:
             raise ValueError("out does not match the plan size %d" % m)
+        self._on_current_stream()
         _lib.check(self._L.mgx_plan_get_dev(self._h, out.data_ptr()))
         return out
+
+    def tune(self, Ndown, Nup, omega):
+        """Measure the launch shapes of the level-0 launches of V(Ndown,Nup) cycles now
+        (mgx_plan_tune); the data in the plan is left as it was."""
+        self._on_current_stream()
+        _lib.check(self._L.mgx_plan_tune(self._h, Ndown, Nup, omega))
 
     def profile(self, enable=True):
         """Start (and reset) or stop per-launch timing of the fine-level kernels."""
@@ -277,6 +290,7 @@ class Plan:
     def cycles(self, Nv, Ndown, Nup, omega, pureJacobi=False):
         res = np.zeros(Nv + 1)
         tim = np.zeros(Nv + 1)
+        self._on_current_stream()
         _lib.check(self._L.mgx_plan_cycles(self._h, Nv, Ndown, Nup, omega, int(bool(pureJacobi)),
                                            res.ctypes.data, tim.ctypes.data))
         return MGOutputs(res, tim)
@@ -288,6 +302,7 @@ class Plan:
         boundary values of v are used.  Returns the finest level's MGOutputs (ncyc+1 entries)."""
         res = np.zeros(ncyc + 1)
         tim = np.zeros(ncyc + 1)
+        self._on_current_stream()
         _lib.check(self._L.mgx_plan_fmg(self._h, ncyc, Ndown, Nup, omega, res.ctypes.data, tim.ctypes.data))
         return MGOutputs(res, tim)
 
@@ -339,6 +354,8 @@ def solve_host(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pureJacobi=False, sc
     f = np.asfortranarray(f, dtype=np.float64)
     if not (isinstance(v, np.ndarray) and v.dtype == np.float64 and v.flags.f_contiguous):
         raise TypeError("v must be a Fortran-ordered float64 numpy array (it is written in place)")
+    if f.ndim != 2 or v.shape != f.shape:
+        raise ValueError("f %s and v %s must be 2-D arrays of one shape" % (f.shape, v.shape))
     m, n = f.shape
     res = np.zeros(Nv + 1)
     tim = np.zeros(Nv + 1)
