@@ -227,6 +227,17 @@ int mgx_norminf(const double *a_dev, size_t len, double *out_host, void *stream)
  * (main.cpp:307,351). */
 int mgx_residual_norm(const double *v_dev, const double *f_dev, int m, double dx, double *out_host, void *stream);
 
+/* calcNorm(residual(p)) like mgx_residual_norm(), for callers that cannot allocate.  This
+ * entry point has no counterpart in the reference; it exists for code under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc/hipFree: it allocates
+ * nothing, synchronises nothing and leaves the result in DEVICE memory (*norm_dev, one
+ * double), stream-ordered on `stream`.  Its partial results live in a fixed 64 KiB device
+ * array inside the library (one per GPU, held until the process ends), which bounds the grid
+ * it accepts: m <= 65537, larger sizes are rejected with MGX_ERR_ARG.  All calls on one GPU
+ * share that array: calls that overlap on one GPU (different streams or threads) race. */
+int mgx_residual_norm_noalloc(const double *v_dev, const double *f_dev, int m, double dx, double *norm_dev,
+                              void *stream);
+
 /* ---- fused legs (what the default schedule runs on every level) ------------ */
 
 /* Down leg of one level in one pass over HBM: relax(nsweeps) + residual +

@@ -99,6 +99,7 @@ SIGNATURES = {
     "mgx_norm_decode": (ctypes.c_double, [ctypes.c_ulonglong]),
     "mgx_plan_vcycle_async": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
     "mgx_residual_norm": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
+    "mgx_residual_norm_noalloc": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
     "mgx_plan_tune": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     "mgx_tune_mode": (ctypes.c_int, [ctypes.c_int]),
     "mgx_tune_reset": (ctypes.c_int, []),

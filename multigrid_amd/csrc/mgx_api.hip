@@ -22,11 +22,13 @@ namespace {
 
 thread_local char g_err[512] = "";
 
+void set_error(const char *fmt, va_list ap) { vsnprintf(g_err, sizeof(g_err), fmt, ap); }
+
 int fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    set_error(fmt, ap);
     va_end(ap);
     return code;
 }
@@ -65,6 +67,15 @@ struct Level {
 };
 
 } // namespace
+
+int mgx::api_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    set_error(fmt, ap);
+    va_end(ap);
+    return code;
+}
 
 struct mgx_plan {
     int device = 0;

@@ -29,6 +29,38 @@ __host__ __device__ inline double norm_decode(unsigned long long k)
     return x.d;
 }
 
+// ---- device helpers shared by the per-operator kernels ------------------------------
+// residual at flat index k of an m-row grid, main.cpp:277: f - (uW+uE+uS+uN - u*4.0)*invh2
+__device__ __forceinline__ double residual_at(const double *__restrict__ u, const double *__restrict__ f, size_t k,
+                                              int m, double invh2)
+{
+    double s = u[k - 1] + u[k + 1];
+    s = s + u[k - m];
+    s = s + u[k + m];
+    s = s - u[k] * 4.0;
+    s = s * invh2;
+    return f[k] - s;
+}
+
+__device__ __forceinline__ double absmax_step(double acc, double v)
+{
+    const double a = __builtin_fabs(v);
+    return (acc < a) ? a : acc;  // NaN never wins, as `maxV < v ? v : maxV` (DTDoubleArray.cpp:895)
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off, 64);
+        v = (v < o) ? o : v;
+    }
+    return v;
+}
+
+// sets the calling thread's mgx_last_error() text and returns `code` (mgx_api.hip)
+int api_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
 struct SweepCoef {
     double h2;      // dx*dx                     (main.cpp:180)
     double invh2;   // 1.0/h2                    (main.cpp:268)

@@ -56,17 +56,6 @@ hipError_t launch_jacobi(const double *uin, double *uout, const double *f, int m
 // Columns [jlo,jhi): rows 1..m-2 get the residual, rows 0 and m-1 get 0
 // (main.cpp:267).  Boundary COLUMNS are zeroed by the caller (memset).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double residual_at(const double *__restrict__ u, const double *__restrict__ f, size_t k,
-                                              int m, double invh2)
-{
-    double s = u[k - 1] + u[k + 1];
-    s = s + u[k - m];
-    s = s + u[k + m];
-    s = s - u[k] * 4.0;
-    s = s * invh2;
-    return f[k] - s;
-}
-
 __global__ __launch_bounds__(BX * BY) void k_residual(const double *__restrict__ u, const double *__restrict__ f,
                                                       double *__restrict__ r, int m, int jlo, int jhi, SweepCoef c)
 {
@@ -245,22 +234,6 @@ hipError_t launch_inject_boundary(const double *fine, int mf, double *coarse, in
 // shuffles, one LDS hop across the workgroup's 4 waves, then ONE atomic max
 // per workgroup on the order-preserving integer image of the value.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double absmax_step(double acc, double v)
-{
-    const double a = __builtin_fabs(v);
-    return (acc < a) ? a : acc;  // NaN never wins, as `maxV < v ? v : maxV`
-}
-
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(v, off, 64);
-        v = (v < o) ? o : v;
-    }
-    return v;
-}
-
 __device__ __forceinline__ void block_max_to_slot(double acc, unsigned long long *slot)
 {
     __shared__ double wmax[16];
