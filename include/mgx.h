@@ -45,7 +45,12 @@ typedef struct mgx_options {
                          2 = fused streaming kernels                                            */
     int verbose;      /* 1 = print the reference's "Direct solver not defined" message etc.     */
     int coarse_solve; /* MGX_COARSE_REFERENCE (0, default) or MGX_COARSE_EXACT, see below           */
-    int reserved[7];
+    int ngpus;        /* mgx_solve2d: 0 or 1 = one device (default); N > 1 = the grid is split into
+                         N j-slabs, slab k on device k modulo the number of visible devices
+                         (mgx_mplan_*, below).  A grid too small to split runs on one device.   */
+    int tail_m;       /* partitioned runs: largest level (points per side) that every slab
+                         holds whole instead of a share of; 0 = default (1025, MGX_TAIL_M)      */
+    int reserved[5];
 } mgx_options;
 
 #define MGX_SCHEDULE_DEFAULT 0
@@ -316,6 +321,66 @@ double mgx_norm_decode(unsigned long long slot);
  * taken to be all zeros, as a coarse level is when the down sweep reaches it
  * (main.cpp:295-299,345); its Dirichlet boundary must then be zero too. */
 int mgx_plan_vcycle_async(mgx_plan *plan, int Ndown, int Nup, double omega, int zero_guess);
+
+/* ------------------------------------------------------------------------
+ * Partitioned plan: the same V-cycle over N j-slabs driven from ONE process, one host
+ * thread, one compute stream and one copy stream per slab.  The reference is a
+ * single-device program (main.cpp); this has no counterpart there except the results it
+ * must reproduce: Sol and ResNorms are bit-identical to mgx_plan_* for any N.
+ *   devices[nslabs]   HIP ordinal of each slab's device, NULL = slab k on device k modulo
+ *                     the number of visible devices.  An ordinal may repeat: several slabs
+ *                     then share a GPU (how the partitioned schedule runs on fewer GPUs).
+ * Levels above options.tail_m are split (slab g owns a contiguous range of columns, the
+ * owner of fine column 2J owns coarse column J); the levels below are held and computed by
+ * every slab.  Per cycle with Ndown + Nup <= 4: one neighbour exchange (peer copies of
+ * 8 columns of the level-0 iterate + a few of the level-1 right-hand side, overlapped with
+ * the interior of the level-0 launch) and one gather of the tail's right-hand side.
+ * Only the fused schedule exists here; options.schedule = MGX_SCHEDULE_STEPWISE is
+ * rejected.  A grid that cannot be split (fewer than a halo's worth of columns per slab
+ * above tail_m) is rejected with MGX_ERR_ARG: use mgx_plan_*.  After a failed call the plan
+ * must be destroyed.
+ * ------------------------------------------------------------------------ */
+typedef struct mgx_mplan mgx_mplan;
+int mgx_mplan_create(mgx_mplan **plan, int m, double dx, int coarsest, int nslabs, const int *devices,
+                     const mgx_options *opt);
+int mgx_mplan_destroy(mgx_mplan *plan);
+int mgx_mplan_nslabs(const mgx_mplan *plan);
+int mgx_mplan_depth(const mgx_mplan *plan);
+int mgx_mplan_distributed_levels(const mgx_mplan *plan); /* levels split over the slabs          */
+int mgx_mplan_tail_m(const mgx_mplan *plan);             /* size of the first level held whole   */
+size_t mgx_mplan_bytes(const mgx_mplan *plan, int slab); /* device memory of one slab            */
+/* Host <-> slabs: f, v are whole m*m column-major host arrays; each slab copies its own
+ * columns (a contiguous block).  Synchronous. */
+int mgx_mplan_upload(mgx_mplan *plan, const double *f_host, const double *v_host);
+int mgx_mplan_download(mgx_mplan *plan, double *v_host);
+/* Device access to one slab's fine-level arrays, for callers that produce f on the GPU:
+ * the slab stores global columns [col_first, col_first + ncols) (its own columns
+ * [own_first, own_first + own_count) plus halo) as an m-row column-major block.  Fill f_dev
+ * and v_dev for ALL stored columns (halo included, or at least the own columns: the halo of
+ * v is refreshed at the start of mgx_mplan_cycles, the halo of f must be right), on `device`,
+ * then call mgx_mplan_commit().  v_dev names the live iterate; ask again after cycles. */
+typedef struct mgx_slab_info {
+    int struct_size;
+    int device, m, col_first, ncols, own_first, own_count;
+    double *f_dev, *v_dev;
+    void *stream; /* the slab's compute stream */
+} mgx_slab_info;
+int mgx_mplan_slab(mgx_mplan *plan, int slab, mgx_slab_info *info);
+int mgx_mplan_commit(mgx_mplan *plan);
+/* Nv cycles: the loop of main.cpp:309-354 over all slabs.  resnorms/times as in
+ * mgx_plan_cycles (times: whole-cycle device time of slab 0).  Synchronous. */
+int mgx_mplan_cycles(mgx_mplan *plan, int Nv, int Ndown, int Nup, double omega, int pure_jacobi, double *resnorms,
+                     double *times);
+/* Measure the launch shapes of every slab's big launches now (see mgx_plan_tune). */
+int mgx_mplan_tune(mgx_mplan *plan, int Ndown, int Nup, double omega);
+/* Per-launch timing of slab 0's level-0 launches (kernel ids as mgx_plan_profile; the
+ * edge-column launches that precede an exchange are not counted); points = grid points the
+ * timed launches produced. */
+int mgx_mplan_profile(mgx_mplan *plan, int enable);
+int mgx_mplan_profile_get(const mgx_mplan *plan, int kernel_id, long *count, double *total_ms, double *points);
+/* Since mgx_mplan_profile(): neighbour exchanges and tail gathers begun; wall seconds of the
+ * last mgx_mplan_cycles() call on the host. */
+int mgx_mplan_stats(const mgx_mplan *plan, long *exchanges, long *gathers, double *host_seconds);
 
 /* Launch-shape tuning.  A fused launch over at least 8 M grid points that streams both the
  * iterate and the right-hand side can run in two or three workgroup shapes that compute

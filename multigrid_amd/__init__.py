@@ -8,11 +8,11 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 from . import _lib
 from ._lib import COARSE_EXACT, COARSE_REFERENCE, MgxError, SCHEDULE_DEFAULT, SCHEDULE_FUSED, SCHEDULE_STEPWISE
-from .solver import (FullMultiGrid, MGOutputs, MultiGrid, Plan, calcNorm, coarse_exact, coarsen, colmajor, direct_solve, fused_down, fused_up,
+from .solver import (FullMultiGrid, MGOutputs, MultiGrid, MultiPlan, Plan, calcNorm, coarse_exact, coarsen, colmajor, direct_solve, fused_down, fused_up,
                      gridtype, prolong_add, refine, relax, residual, residual_norm, solve_host, to_device, to_numpy)
 
 __all__ = [
-    "FullMultiGrid", "COARSE_EXACT", "COARSE_REFERENCE", "coarse_exact", "MgxError", "SCHEDULE_DEFAULT", "SCHEDULE_FUSED", "SCHEDULE_STEPWISE", "MGOutputs", "MultiGrid", "Plan",
+    "FullMultiGrid", "COARSE_EXACT", "COARSE_REFERENCE", "coarse_exact", "MgxError", "SCHEDULE_DEFAULT", "SCHEDULE_FUSED", "SCHEDULE_STEPWISE", "MGOutputs", "MultiGrid", "MultiPlan", "Plan",
     "calcNorm", "coarsen", "colmajor", "direct_solve", "fused_down", "fused_up", "gridtype", "prolong_add", "refine", "relax", "residual",
     "residual_norm", "solve_host", "to_device", "to_numpy",
 ]

@@ -28,7 +28,18 @@ class mgx_options(ctypes.Structure):
         ("schedule", ctypes.c_int),
         ("verbose", ctypes.c_int),
         ("coarse_solve", ctypes.c_int),
-        ("reserved", ctypes.c_int * 7),
+        ("ngpus", ctypes.c_int),
+        ("tail_m", ctypes.c_int),
+        ("reserved", ctypes.c_int * 5),
+    ]
+
+
+class mgx_slab_info(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_int),
+        ("device", ctypes.c_int), ("m", ctypes.c_int), ("col_first", ctypes.c_int), ("ncols", ctypes.c_int),
+        ("own_first", ctypes.c_int), ("own_count", ctypes.c_int),
+        ("f_dev", ctypes.c_void_p), ("v_dev", ctypes.c_void_p), ("stream", ctypes.c_void_p),
     ]
 
 
@@ -100,6 +111,26 @@ SIGNATURES = {
     "mgx_plan_vcycle_async": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
     "mgx_residual_norm": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
     "mgx_residual_norm_noalloc": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, _vp, _vp]),
+    "mgx_mplan_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                        _vp, _vp]),
+    "mgx_mplan_destroy": (ctypes.c_int, [_vp]),
+    "mgx_mplan_nslabs": (ctypes.c_int, [_vp]),
+    "mgx_mplan_depth": (ctypes.c_int, [_vp]),
+    "mgx_mplan_distributed_levels": (ctypes.c_int, [_vp]),
+    "mgx_mplan_tail_m": (ctypes.c_int, [_vp]),
+    "mgx_mplan_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int]),
+    "mgx_mplan_upload": (ctypes.c_int, [_vp, _vp, _vp]),
+    "mgx_mplan_download": (ctypes.c_int, [_vp, _vp]),
+    "mgx_mplan_slab": (ctypes.c_int, [_vp, ctypes.c_int, _vp]),
+    "mgx_mplan_commit": (ctypes.c_int, [_vp]),
+    "mgx_mplan_cycles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                        _vp, _vp]),
+    "mgx_mplan_tune": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
+    "mgx_mplan_profile": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mgx_mplan_profile_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_long),
+                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "mgx_mplan_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long),
+                                       ctypes.POINTER(ctypes.c_double)]),
     "mgx_plan_tune": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     "mgx_tune_mode": (ctypes.c_int, [ctypes.c_int]),
     "mgx_tune_reset": (ctypes.c_int, []),
@@ -135,7 +166,7 @@ def check(rc):
     return rc
 
 
-def make_options(device=-1, stream=None, schedule=SCHEDULE_DEFAULT, verbose=0, coarse_solve=0):
+def make_options(device=-1, stream=None, schedule=SCHEDULE_DEFAULT, verbose=0, coarse_solve=0, ngpus=0, tail_m=0):
     o = mgx_options()
     o.struct_size = ctypes.sizeof(mgx_options)
     o.device = device
@@ -143,4 +174,6 @@ def make_options(device=-1, stream=None, schedule=SCHEDULE_DEFAULT, verbose=0, c
     o.schedule = schedule
     o.verbose = verbose
     o.coarse_solve = coarse_solve
+    o.ngpus = ngpus
+    o.tail_m = tail_m
     return o

@@ -982,6 +982,21 @@ int mgx_solve2d(const double *f, double *v, int m, int n, double dx,
 {
     if (!f || !v) return fail(MGX_ERR_ARG, "mgx_solve2d: null f or v");
     if (m != n) return fail(MGX_ERR_ARG, "mgx_solve2d: Input is not square matrix! (%dx%d)", m, n);  // main.cpp:408-412
+    if (opt && opt->struct_size == (int)sizeof(mgx_options) && opt->ngpus > 1 &&
+        opt->schedule != MGX_SCHEDULE_STEPWISE) {
+        // the grid split into opt->ngpus j-slabs, one per device; a grid too small to split
+        // (MGX_ERR_ARG from the partitioned plan) runs on one device like any other
+        mgx_mplan *mp = nullptr;
+        int rc = mgx_mplan_create(&mp, m, dx, coarsest, opt->ngpus, nullptr, opt);
+        if (rc == MGX_OK) {
+            rc = mgx_mplan_upload(mp, f, v);
+            if (!rc) rc = mgx_mplan_cycles(mp, Nv, Ndown, Nup, omega, pure_jacobi, resnorms, times);
+            if (!rc) rc = mgx_mplan_download(mp, v);
+            mgx_mplan_destroy(mp);
+            return rc;
+        }
+        if (rc != MGX_ERR_ARG) return rc;
+    }
     mgx_plan *p = nullptr;
     int rc = mgx_plan_create(&p, m, dx, coarsest, opt);
     if (rc) return rc;

@@ -86,6 +86,8 @@ hipError_t launch_refine(const double *coarse, int mc, double *fine, int mf, int
 hipError_t launch_direct3x3(double *v, const double *f, double h2, hipStream_t s);
 // boundary entries of an m x m array: x <- x + 0.0 (what main.cpp:341 does to them)
 hipError_t launch_boundary_plus_zero(double *v, int m, hipStream_t s);
+// the same for a slab of ncols columns; jfix_lo / jfix_hi: local physical boundary columns or -1
+hipError_t launch_slab_boundary_plus_zero(double *v, int m, int ncols, int jfix_lo, int jfix_hi, hipStream_t s);
 // full multigrid: coarse boundary point k <- fine boundary point 2k (all four sides)
 hipError_t launch_inject_boundary(const double *fine, int mf, double *coarse, int mc, hipStream_t s);
 hipError_t launch_norminf(const double *a, size_t len, unsigned long long *slot, hipStream_t s);

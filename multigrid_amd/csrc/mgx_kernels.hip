@@ -220,6 +220,31 @@ hipError_t launch_boundary_plus_zero(double *v, int m, hipStream_t s)
     return hipGetLastError();
 }
 
+// The same for a slab (m rows, ncols columns, pitch m): the boundary rows 0 and m-1 of every
+// column it holds, and the whole of a physical boundary column (local index jfix_lo /
+// jfix_hi, or -1).  Row entries of a fixed column are visited by the column pass only.
+__global__ void k_slab_boundary_plus_zero(double *__restrict__ v, int m, int ncols, int jfix_lo, int jfix_hi)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t ld = (size_t)m;
+    if (k < ncols && k != jfix_lo && k != jfix_hi) {
+        v[(size_t)k * ld] = v[(size_t)k * ld] + 0.0;
+        v[(size_t)k * ld + (ld - 1)] = v[(size_t)k * ld + (ld - 1)] + 0.0;
+    }
+    if (k < m) {
+        if (jfix_lo >= 0) v[(size_t)jfix_lo * ld + k] = v[(size_t)jfix_lo * ld + k] + 0.0;
+        if (jfix_hi >= 0 && jfix_hi != jfix_lo) v[(size_t)jfix_hi * ld + k] = v[(size_t)jfix_hi * ld + k] + 0.0;
+    }
+}
+
+hipError_t launch_slab_boundary_plus_zero(double *v, int m, int ncols, int jfix_lo, int jfix_hi, hipStream_t s)
+{
+    const int n = m > ncols ? m : ncols;
+    hipLaunchKernelGGL(k_slab_boundary_plus_zero, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, m, ncols,
+                       jfix_lo, jfix_hi);
+    return hipGetLastError();
+}
+
 hipError_t launch_inject_boundary(const double *fine, int mf, double *coarse, int mc, hipStream_t s)
 {
     hipLaunchKernelGGL(k_inject_boundary, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, s, fine, mf, coarse, mc);

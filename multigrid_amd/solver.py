@@ -307,6 +307,124 @@ class Plan:
         return MGOutputs(res, tim)
 
 
+class MultiPlan:
+    """The grid split into j-slabs over several devices, driven from this one process
+    (mgx_mplan_*): one host thread and two streams per slab inside the library, halo columns
+    pulled with peer copies.  `devices` lists the HIP ordinal of each slab's device and may
+    repeat an ordinal (several slabs on one GPU); None puts slab k on device k modulo the
+    number of visible devices.  Results are bit-identical to Plan for any number of slabs."""
+
+    def __init__(self, m, dx, coarsest=2, nslabs=2, devices=None, tail_m=0, verbose=0,
+                 coarse_solve=_lib.COARSE_REFERENCE):
+        _require_gpu()
+        self._L = _lib.load()
+        self._h = ctypes.c_void_p()
+        self.m, self.dx = m, dx
+        opt = _lib.make_options(verbose=verbose, coarse_solve=coarse_solve, tail_m=tail_m)
+        devs = None
+        if devices is not None:
+            if len(devices) != nslabs:
+                raise ValueError("devices must name one device per slab")
+            devs = (ctypes.c_int * nslabs)(*devices)
+        _lib.check(self._L.mgx_mplan_create(ctypes.byref(self._h), m, dx, coarsest, nslabs, devs, ctypes.byref(opt)))
+
+    def close(self):
+        if self._h:
+            self._L.mgx_mplan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    nslabs = property(lambda self: self._L.mgx_mplan_nslabs(self._h))
+    depth = property(lambda self: self._L.mgx_mplan_depth(self._h))
+    ndist = property(lambda self: self._L.mgx_mplan_distributed_levels(self._h))
+    tail_m = property(lambda self: self._L.mgx_mplan_tail_m(self._h))
+
+    def slab(self, k):
+        """mgx_slab_info of slab k (device, stored and owned columns, device pointers)."""
+        info = _lib.mgx_slab_info()
+        info.struct_size = ctypes.sizeof(_lib.mgx_slab_info)
+        _lib.check(self._L.mgx_mplan_slab(self._h, k, ctypes.byref(info)))
+        return info
+
+    def upload(self, f, v):
+        """f, v: Fortran-ordered float64 m x m host arrays; every slab takes its columns."""
+        f = np.asfortranarray(f, dtype=np.float64)
+        v = np.asfortranarray(v, dtype=np.float64)
+        if f.shape != (self.m, self.m) or v.shape != (self.m, self.m):
+            raise ValueError("f and v must be %d x %d" % (self.m, self.m))
+        _lib.check(self._L.mgx_mplan_upload(self._h, f.ctypes.data, v.ctypes.data))
+
+    def download(self, out=None):
+        if out is None:
+            out = np.empty((self.m, self.m), order="F")
+        elif not (out.dtype == np.float64 and out.flags.f_contiguous and out.shape == (self.m, self.m)):
+            raise TypeError("out must be a Fortran-ordered float64 m x m array")
+        _lib.check(self._L.mgx_mplan_download(self._h, out.ctypes.data))
+        return out
+
+    def set_random_rhs(self):
+        """Benchmark input: the splitmix64 random right-hand side generated on each slab's
+        device for the columns it stores, zero guess."""
+        from . import rhs
+        for k in range(self.nslabs):
+            s = self.slab(k)
+            dev = torch.device("cuda", s.device)
+            with torch.cuda.device(dev):
+                f = torch.as_tensor(_DevPtr(s.f_dev, (s.ncols, s.m)), device=dev)
+                v = torch.as_tensor(_DevPtr(s.v_dev, (s.ncols, s.m)), device=dev)
+                f.copy_(rhs.random_torch_cols(self.m, s.col_first, s.col_first + s.ncols, device=dev))
+                v.zero_()
+                torch.cuda.synchronize(dev)
+        _lib.check(self._L.mgx_mplan_commit(self._h))
+
+    def tune(self, Ndown, Nup, omega):
+        _lib.check(self._L.mgx_mplan_tune(self._h, Ndown, Nup, omega))
+
+    def cycles(self, Nv, Ndown, Nup, omega, pureJacobi=False):
+        res = np.zeros(Nv + 1)
+        tim = np.zeros(Nv + 1)
+        _lib.check(self._L.mgx_mplan_cycles(self._h, Nv, Ndown, Nup, omega, int(bool(pureJacobi)),
+                                            res.ctypes.data, tim.ctypes.data))
+        return MGOutputs(res, tim)
+
+    def profile(self, enable=True):
+        _lib.check(self._L.mgx_mplan_profile(self._h, int(bool(enable))))
+
+    def profile_totals(self):
+        out = {}
+        self._pts = {}
+        for k in range(_lib.KERNEL_COUNT):
+            n, ms, pts = ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+            _lib.check(self._L.mgx_mplan_profile_get(self._h, k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(pts)))
+            if n.value:
+                name = self._L.mgx_kernel_name(k).decode()
+                out[name] = (n.value, ms.value)
+                self._pts[name] = pts.value
+        return out
+
+    def profile_points(self):
+        return dict(getattr(self, "_pts", {}))
+
+    def stats(self):
+        """(neighbour exchanges, tail gathers, host wall seconds of the last cycles() call)."""
+        x, g, t = ctypes.c_long(0), ctypes.c_long(0), ctypes.c_double(0.0)
+        _lib.check(self._L.mgx_mplan_stats(self._h, ctypes.byref(x), ctypes.byref(g), ctypes.byref(t)))
+        return x.value, g.value, t.value
+
+
+class _DevPtr:
+    """Lets torch wrap device memory owned by libmgx as a tensor without copying."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
 def FullMultiGrid(prob, ncyc, Ndown, Nup, omega, coarsest, schedule=_lib.SCHEDULE_DEFAULT,
                   coarse_solve=_lib.COARSE_REFERENCE):
     """EXTENSION: Plan.fmg() on a gridtype; prob.v (boundary values in, interior ignored) is
@@ -347,10 +465,12 @@ def MultiGrid(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi=False, schedule=
 
 
 def solve_host(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pureJacobi=False, schedule=_lib.SCHEDULE_DEFAULT,
-               coarse_solve=_lib.COARSE_REFERENCE):
+               coarse_solve=_lib.COARSE_REFERENCE, ngpus=0, tail_m=0):
     """mgx_solve2d on host numpy arrays (the drop-in for main.cpp:445).
 
-    f, v: Fortran-ordered float64 m x n; v is overwritten.  Returns MGOutputs."""
+    f, v: Fortran-ordered float64 m x n; v is overwritten.  Returns MGOutputs.  ngpus > 1 splits
+    the grid into that many j-slabs (mgx_options.ngpus), tail_m sets the largest level every
+    slab holds whole."""
     f = np.asfortranarray(f, dtype=np.float64)
     if not (isinstance(v, np.ndarray) and v.dtype == np.float64 and v.flags.f_contiguous):
         raise TypeError("v must be a Fortran-ordered float64 numpy array (it is written in place)")
@@ -360,7 +480,7 @@ def solve_host(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pureJacobi=False, sc
     res = np.zeros(Nv + 1)
     tim = np.zeros(Nv + 1)
     L = _lib.load()
-    opt = _lib.make_options(schedule=schedule, coarse_solve=coarse_solve)
+    opt = _lib.make_options(schedule=schedule, coarse_solve=coarse_solve, ngpus=ngpus, tail_m=tail_m)
     _lib.check(L.mgx_solve2d(f.ctypes.data, v.ctypes.data, m, n, dx, Nv, Ndown, Nup, omega, coarsest,
                              int(bool(pureJacobi)), res.ctypes.data, tim.ctypes.data, ctypes.byref(opt)))
     return MGOutputs(res, tim)

@@ -1,0 +1,158 @@
+"""GPU tests of the partitioned plan (mgx_mplan_*, the ngpus option of mgx_solve2d): the
+V-cycle over N j-slabs driven from one process.  The test box has one GPU, so the slabs
+share it (devices may repeat an ordinal): the schedule, ownership, halo pulls, tail gather
+and the thread/event hand-shakes are the ones a multi-GPU node runs, the copies are
+device-to-device instead of peer-to-peer.  Sol and ResNorms must equal the single-process
+CPU oracle bit for bit for every number of slabs."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(M, zero_guess=False):
+    from multigrid_amd import rhs
+    f = rhs.random_np(M)
+    rng = np.random.default_rng(M)
+    v0 = np.zeros((M, M), order="F")
+    v0[0, :], v0[-1, :], v0[:, 0], v0[:, -1] = rng.standard_normal((4, M))   # non-zero Dirichlet data
+    if not zero_guess:
+        v0[1:-1, 1:-1] = rng.standard_normal((M - 2, M - 2)) * 0.01          # and a non-zero guess
+    v0[0, 3] = v0[5, 0] = v0[-1, -1] = v0[-1, 7] = v0[M // 2, -1] = -0.0     # main.cpp:341 turns these into +0.0
+    return f, v0
+
+
+@pytest.mark.parametrize("R,M,tail_m,Nv,nd,nu", [
+    (1, 257, 33, 3, 2, 2), (2, 513, 65, 3, 2, 2), (3, 1025, 129, 3, 2, 2), (4, 2049, 257, 3, 2, 2),
+    (8, 4097, 257, 3, 2, 2), (2, 1025, 65, 4, 1, 2), (3, 1025, 129, 3, 2, 1), (2, 513, 65, 3, 0, 2),
+    (2, 513, 65, 3, 2, 0), (2, 513, 65, 2, 1, 0), (2, 513, 65, 3, 3, 1), (4, 2049, 129, 2, 4, 0),
+    (2, 513, 65, 3, 5, 6), (3, 1025, 129, 2, 3, 3), (2, 513, 65, 2, 0, 0), (5, 4097, 513, 2, 2, 2),
+])
+def test_slabs_in_one_process_match_the_oracle(mg, O, R, M, tail_m, Nv, nd, nu):
+    f, v0 = _problem(M)
+    dx = 1.0 / (M - 1)
+    P = mg.MultiPlan(M, dx, 2, nslabs=R, devices=[0] * R, tail_m=tail_m)
+    assert P.nslabs == R and P.tail_m <= tail_m and P.ndist >= 1
+    P.upload(f, v0)
+    out = P.cycles(Nv, nd, nu, 0.6)
+    sol = P.download()
+    P.close()
+    ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, 0.6, 2, omp=M > 1025)
+    assert_bits(out.ResidualNorms, ref_rn, "ResNorms R=%d" % R)
+    assert_bits(sol, ref_sol, "Sol R=%d" % R)
+    assert out.Times[0] == 0 and np.all(np.diff(out.Times) > 0)
+
+
+@pytest.mark.parametrize("R", [2, 3])
+def test_pure_jacobi_and_split_calls(mg, O, R):
+    M = 513
+    f, v0 = _problem(M)
+    dx = 1.0 / (M - 1)
+    P = mg.MultiPlan(M, dx, 2, nslabs=R, devices=[0] * R, tail_m=65)
+    P.upload(f, v0)
+    out = P.cycles(4, 2, 2, 0.6, pureJacobi=True)
+    ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, 4, 2, 2, 0.6, 2, pure_jacobi=True)
+    assert_bits(out.ResidualNorms, ref_rn, "pureJacobi ResNorms")
+    assert_bits(P.download(), ref_sol, "pureJacobi Sol")
+    # 3 + 2 cycles equal one call of 5, and zero cycles return the initial norm only
+    P.upload(f, v0)
+    a = P.cycles(3, 2, 2, 0.6)
+    z = P.cycles(0, 2, 2, 0.6)
+    b = P.cycles(2, 2, 2, 0.6)
+    ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, 5, 2, 2, 0.6, 2)
+    assert_bits(np.concatenate([a.ResidualNorms, b.ResidualNorms[1:]]), ref_rn, "split ResNorms")
+    assert z.ResidualNorms.shape == (1,) and z.ResidualNorms[0] == a.ResidualNorms[-1]
+    assert_bits(P.download(), ref_sol, "split Sol")
+    P.close()
+
+
+def test_solve2d_with_the_ngpus_option(mg, O):
+    """The call a reference-side shim makes (main.cpp:445 -> mgx_solve2d) with
+    options.ngpus = 4: four slabs (on the one GPU of the box), same bits; a grid too small to
+    split takes the single-device path."""
+    M = 1025
+    f, v0 = _problem(M)
+    dx = 1.0 / (M - 1)
+    ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, 4, 2, 2, 0.6, 2)
+    v = v0.copy(order="F")
+    out = mg.solve_host(f, v, dx, 4, 2, 2, 0.6, 2, ngpus=4, tail_m=129)
+    assert_bits(out.ResidualNorms, ref_rn, "ResNorms ngpus=4")
+    assert_bits(v, ref_sol, "Sol ngpus=4")
+    M = 65
+    f, v0 = _problem(M)
+    ref_sol, ref_rn, _ = O.multigrid(f, v0, 1.0 / 64, 3, 2, 2, 0.6, 2)
+    v = v0.copy(order="F")
+    out = mg.solve_host(f, v, 1.0 / 64, 3, 2, 2, 0.6, 2, ngpus=8)
+    assert_bits(out.ResidualNorms, ref_rn, "ResNorms small grid")
+    assert_bits(v, ref_sol, "Sol small grid")
+    with pytest.raises(mg.MgxError):
+        mg.MultiPlan(65, 1.0 / 64, 2, nslabs=8, devices=[0] * 8)
+
+
+def test_exact_coarsest_solve_and_even_coarsest_level(mg, O):
+    """705 = 11*2^6+1, coarsest 11: levels ... 23, 12; every slab's tail solves the 12x12 grid exactly."""
+    M = 705
+    f, v0 = _problem(M)
+    dx = 1.0 / (M - 1)
+    P = mg.MultiPlan(M, dx, 11, nslabs=2, devices=[0, 0], tail_m=89, coarse_solve=mg.COARSE_EXACT)
+    P.upload(f, v0)
+    out = P.cycles(4, 2, 2, 0.6)
+    sol = P.download()
+    P.close()
+    ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, 4, 2, 2, 0.6, 11, coarse_exact=True)
+    assert np.allclose(out.ResidualNorms, ref_rn, rtol=1e-6, atol=1e-9 * ref_rn[0])
+    assert np.abs(sol - ref_sol).max() <= 1e-9 * np.abs(ref_sol).max()
+    # the reference's behaviour (12x12 left alone): bit for bit
+    P = mg.MultiPlan(M, dx, 11, nslabs=3, devices=[0] * 3, tail_m=89)
+    P.upload(f, v0)
+    out = P.cycles(3, 2, 2, 0.6)
+    ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, 3, 2, 2, 0.6, 11)
+    assert_bits(out.ResidualNorms, ref_rn, "ResNorms")
+    assert_bits(P.download(), ref_sol, "Sol")
+    P.close()
+
+
+@pytest.mark.parametrize("R", [2, 8])
+def test_16385_partitioned_equals_the_single_plan(mg, R):
+    """The benchmark size over 2 and 8 slabs (tail from 1025^2), device-generated right-hand
+    side, tuned launch shapes: residual history and every column of the solution equal the
+    single-device plan's, bit for bit."""
+    import torch
+    from multigrid_amd import rhs
+    from multigrid_amd.solver import _DevPtr
+    M, Nv = 16385, 6
+    dx = 1.0 / (M - 1)
+    plan = mg.Plan(M, dx, 2)
+    plan.set(rhs.random_torch(M), mg.colmajor(M, M))
+    ref = plan.cycles(Nv, 2, 2, 0.6)
+    want = plan.get()
+    P = mg.MultiPlan(M, dx, 2, nslabs=R, devices=[0] * R)
+    assert P.ndist == 4 and P.tail_m == 1025
+    P.set_random_rhs()
+    P.tune(2, 2, 0.6)
+    out = P.cycles(Nv, 2, 2, 0.6)
+    assert_bits(out.ResidualNorms, ref.ResidualNorms, "ResNorms 16385 R=%d" % R)
+    for k in range(R):
+        s = P.slab(k)
+        v = torch.as_tensor(_DevPtr(s.v_dev, (s.ncols, s.m)), device="cuda")
+        a = s.own_first - s.col_first
+        own = v[a:a + s.own_count]
+        assert torch.equal(own.view(torch.int64), want.t()[s.own_first:s.own_first + s.own_count].view(torch.int64))
+    x, g, _ = P.stats()
+    P.close()
+    plan.close()
+
+
+def test_exchange_and_gather_counts(mg):
+    """Lean schedule: one neighbour exchange and one gather per cycle (plus the exchange before
+    the initial norm and the one after the closing up leg)."""
+    M = 2049
+    P = mg.MultiPlan(M, 1.0 / (M - 1), 2, nslabs=4, devices=[0] * 4, tail_m=257)
+    P.set_random_rhs()
+    P.profile(True)
+    P.cycles(5, 2, 2, 0.6)
+    x, g, host = P.stats()
+    assert g == 5 and x == 1 + 5 + 1 and host > 0
+    P.close()
