@@ -378,9 +378,12 @@ int mgx_mplan_tune(mgx_mplan *plan, int Ndown, int Nup, double omega);
  * timed launches produced. */
 int mgx_mplan_profile(mgx_mplan *plan, int enable);
 int mgx_mplan_profile_get(const mgx_mplan *plan, int kernel_id, long *count, double *total_ms, double *points);
-/* Since mgx_mplan_profile(): neighbour exchanges and tail gathers begun; wall seconds of the
- * last mgx_mplan_cycles() call on the host. */
-int mgx_mplan_stats(const mgx_mplan *plan, long *exchanges, long *gathers, double *host_seconds);
+/* Since mgx_mplan_profile(): neighbour exchanges and tail gathers begun; of the last
+ * mgx_mplan_cycles() call: its wall seconds on the host, and how much of that slab 0's thread
+ * needed to enqueue its work (hand-shakes with the neighbours' threads included) before it
+ * started waiting for its device -- the host cost of the driver. */
+int mgx_mplan_stats(const mgx_mplan *plan, long *exchanges, long *gathers, double *host_seconds,
+                    double *enqueue_seconds);
 
 /* Launch-shape tuning.  A fused launch over at least 8 M grid points that streams both the
  * iterate and the right-hand side can run in two or three workgroup shapes that compute

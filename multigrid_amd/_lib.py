@@ -130,7 +130,7 @@ SIGNATURES = {
     "mgx_mplan_profile_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_long),
                                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "mgx_mplan_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long),
-                                       ctypes.POINTER(ctypes.c_double)]),
+                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "mgx_plan_tune": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     "mgx_tune_mode": (ctypes.c_int, [ctypes.c_int]),
     "mgx_tune_reset": (ctypes.c_int, []),

@@ -45,6 +45,12 @@ public:
         fp_ = fopen(path.c_str(), "rb");
         if (!fp_) return;
         static const int sizes[10] = {8, 4, 4, 2, 2, 1, -1, -1, -1, -1};
+        long file_size = 0;
+        if (fseek(fp_, 0, SEEK_END) == 0) file_size = ftell(fp_);
+        if (fseek(fp_, 0, SEEK_SET) != 0 || file_size < 0) {
+            error_ = "cannot seek in the file";
+            return;
+        }
         for (;;) {
             const long starts = ftell(fp_);
             int32_t h[5];
@@ -63,11 +69,20 @@ public:
             char name[256];
             if (fread(name, 1, (size_t)h[4], fp_) != (size_t)h[4]) break;
             name[h[4] - 1] = 0;
-            const long esize = (long)sizes[(type % 100) / 10] * h[1] * h[2];
-            if (esize < 0) {
+            if (sizes[(type % 100) / 10] < 0) {
                 error_ = "Unexpected variable type in the file.";
                 break;
             }
+            // dimensions come from the file: negative ones, or more data than the file holds,
+            // end the scan (the sizes below would otherwise wrap or ask for absurd amounts)
+            const long remaining = file_size - (starts + 20 + h[4]);
+            const long width = sizes[(type % 100) / 10];
+            if (h[1] < 0 || h[2] < 0 || remaining < 0 ||
+                (h[1] > 0 && h[2] > 0 && ((long)h[1] > remaining / width || (long)h[2] > remaining / width / (long)h[1]))) {
+                error_ = "A variable's dimensions do not fit the file.";
+                break;
+            }
+            const long esize = width * h[1] * h[2];
             Entry e;
             e.m = h[1];
             e.n = h[2];

@@ -8,7 +8,9 @@
 // 100), -b/--Nbefore (3), -a/--Nafter (3), -o/--omega (0.6), -c/--coarsest (2),
 // -h/--help.  Added: --input / --output file names, --stepwise (one kernel per
 // reference operator instead of the fused schedule), --exact-coarse (solve a
-// coarsest grid other than 3x3 exactly instead of leaving it as it is).
+// coarsest grid other than 3x3 exactly instead of leaving it as it is),
+// --ngpus N (split the grid into N j-slabs, one per device), --tail-m M (largest
+// level every slab holds whole).
 #include "../../include/mgx.h"
 #include "mat4.h"
 
@@ -32,11 +34,13 @@ void usage()
            "  --input arg (=Input.mat)      MAT-v4 file holding f and f_loc\n"
            "  --output arg (=Output.mat)    MAT-v4 file receiving Sol, ResNorms, Times\n"
            "  --stepwise                    one GPU kernel per reference operator\n"
-           "  --exact-coarse                solve a coarsest grid other than 3x3 exactly\n\n");
+           "  --exact-coarse                solve a coarsest grid other than 3x3 exactly\n"
+           "  --ngpus arg (=1)              split the grid into this many j-slabs, one per GPU\n"
+           "  --tail-m arg (=1025)          largest level every slab holds whole\n\n");
 }
 
 struct Args {
-    int Nv = 100, Ndown = 3, Nup = 3, coarsest = 2;
+    int Nv = 100, Ndown = 3, Nup = 3, coarsest = 2, ngpus = 0, tail_m = 0;
     double omega = 0.6;
     std::string input = "Input.mat", output = "Output.mat";
     bool help = false, stepwise = false, exact_coarse = false;
@@ -97,6 +101,8 @@ int parse(int argc, const char *argv[], Args &a)
         else if (key == "Nafter") ok = parse_int(val.c_str(), a.Nup);
         else if (key == "coarsest") ok = parse_int(val.c_str(), a.coarsest);
         else if (key == "omega") ok = parse_double(val.c_str(), a.omega);
+        else if (key == "ngpus") ok = parse_int(val.c_str(), a.ngpus);
+        else if (key == "tail-m") ok = parse_int(val.c_str(), a.tail_m);
         else if (key == "input") a.input = val;
         else if (key == "output") a.output = val;
         else { fprintf(stderr, "unrecognised option '--%s'\n", key.c_str()); return 2; }
@@ -167,6 +173,8 @@ int main(int argc, const char *argv[])
     opt.verbose = 1;  // the reference prints "Direct solver not defined ..." (main.cpp:167)
     opt.schedule = a.stepwise ? MGX_SCHEDULE_STEPWISE : MGX_SCHEDULE_DEFAULT;
     opt.coarse_solve = a.exact_coarse ? MGX_COARSE_EXACT : MGX_COARSE_REFERENCE;
+    opt.ngpus = a.ngpus;
+    opt.tail_m = a.tail_m;
     rc = mgx_solve2d(f.data(), u.data(), M, N, dx, a.Nv, a.Ndown, a.Nup, a.omega, a.coarsest, 0, resnorm.data(),
                      times.data(), &opt);  // main.cpp:445
     if (rc != MGX_OK) {

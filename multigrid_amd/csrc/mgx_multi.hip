@@ -167,7 +167,8 @@ struct mgx_mplan {
     long prof_n[MGX_KERNEL_COUNT] = {0};
     double prof_pts[MGX_KERNEL_COUNT] = {0};
     long nexchanges = 0, ngathers = 0;
-    double host_seconds = 0;  // wall time of the last mgx_mplan_cycles() call
+    double host_seconds = 0;     // wall time of the last mgx_mplan_cycles() call
+    double enqueue_seconds = 0;  // of which slab 0's thread spent enqueuing (hand-shakes included), before it waited for its device
 };
 
 namespace {
@@ -1068,9 +1069,14 @@ static int mplan_run(mgx_mplan *mp, const CycleArgs &a, double *resnorms, double
     const int Nv = a.Nv;
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    const int rc = on_every_slab(mp, [&a](Slab &S) {
+    const int rc = on_every_slab(mp, [&a, mp, t0](Slab &S) {
         const int rc_ = slab_cycles(S, a);
         if (rc_ != MGX_OK) return rc_;
+        if (S.rank == 0) {
+            timespec te;
+            clock_gettime(CLOCK_MONOTONIC, &te);
+            mp->enqueue_seconds = (double)(te.tv_sec - t0.tv_sec) + 1e-9 * (double)(te.tv_nsec - t0.tv_nsec);
+        }
         S_HIP(S, hipStreamSynchronize(S.compute));
         S_HIP(S, hipStreamSynchronize(S.comm));
         return (int)MGX_OK;
@@ -1195,12 +1201,14 @@ int mgx_mplan_profile_get(const mgx_mplan *mp, int kernel_id, long *count, doubl
     return MGX_OK;
 }
 
-int mgx_mplan_stats(const mgx_mplan *mp, long *exchanges, long *gathers, double *host_seconds)
+int mgx_mplan_stats(const mgx_mplan *mp, long *exchanges, long *gathers, double *host_seconds,
+                    double *enqueue_seconds)
 {
     if (!mp) return api_fail(MGX_ERR_ARG, "mgx_mplan_stats: null plan");
     if (exchanges) *exchanges = mp->nexchanges;
     if (gathers) *gathers = mp->ngathers;
     if (host_seconds) *host_seconds = mp->host_seconds;
+    if (enqueue_seconds) *enqueue_seconds = mp->enqueue_seconds;
     return MGX_OK;
 }
 

@@ -411,10 +411,11 @@ class MultiPlan:
         return dict(getattr(self, "_pts", {}))
 
     def stats(self):
-        """(neighbour exchanges, tail gathers, host wall seconds of the last cycles() call)."""
-        x, g, t = ctypes.c_long(0), ctypes.c_long(0), ctypes.c_double(0.0)
-        _lib.check(self._L.mgx_mplan_stats(self._h, ctypes.byref(x), ctypes.byref(g), ctypes.byref(t)))
-        return x.value, g.value, t.value
+        """(neighbour exchanges, tail gathers, wall seconds of the last cycles() call, seconds
+        slab 0's host thread needed to enqueue that call's work)."""
+        x, g, t, q = ctypes.c_long(0), ctypes.c_long(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _lib.check(self._L.mgx_mplan_stats(self._h, ctypes.byref(x), ctypes.byref(g), ctypes.byref(t), ctypes.byref(q)))
+        return x.value, g.value, t.value, q.value
 
 
 class _DevPtr:

@@ -8,7 +8,8 @@
 // Output.mat (main.cpp:391-396,452-455), a zero initial guess with boundary_func == 0 on
 // the boundary (main.cpp:420-439).  Option parsing is positional here because the
 // reference's uses boost, which the image lacks:
-//     dt_dropin Nv Ndown Nup omega coarsest   (cwd holds Input.mat; writes Output.mat)
+//     dt_dropin Nv Ndown Nup omega coarsest [ngpus [tail_m]]   (cwd holds Input.mat; writes Output.mat)
+// ngpus > 1 sets mgx_options.ngpus: the same call then runs over that many j-slabs.
 // tests/test_gpu_dropin.py runs it on the GPU box and compares Output.mat with the oracle.
 #include "DTDoubleArray.h"
 #include "DTMatlabDataFile.h"
@@ -34,16 +35,25 @@ struct MGOutputs {
 
 // Drop-in for main.cpp:283: same signature, same in-place solution, same two output vectors;
 // the body is include/mgx_multigrid.hpp, the binding this repository ships.
+static mgx_options g_options;  // zero = defaults; main() may set ngpus / tail_m
+
 MGOutputs MultiGrid(gridtype &prob, int Nv, int Ndown, int Nup, double omega, int coarsest, bool pureJacobi = false)
 {
-    return mgx::MultiGrid<MGOutputs, DTMutableDoubleArray>(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi);
+    return mgx::MultiGrid<MGOutputs, DTMutableDoubleArray>(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi,
+                                                           g_options.struct_size ? &g_options : NULL);
 }
 
 int main(int argc, char **argv)
 {
-    if (argc != 6) {
-        fprintf(stderr, "usage: dt_dropin Nv Ndown Nup omega coarsest\n");
+    if (argc < 6 || argc > 8) {
+        fprintf(stderr, "usage: dt_dropin Nv Ndown Nup omega coarsest [ngpus [tail_m]]\n");
         return 2;
+    }
+    if (argc > 6) {
+        g_options.struct_size = (int)sizeof(g_options);
+        g_options.device = -1;
+        g_options.ngpus = atoi(argv[6]);
+        g_options.tail_m = argc > 7 ? atoi(argv[7]) : 0;
     }
     const int Nv = atoi(argv[1]), Ndown = atoi(argv[2]), Nup = atoi(argv[3]), coarsest = atoi(argv[5]);
     const double omega = atof(argv[4]);

@@ -126,3 +126,14 @@ def test_exact_coarse_flag(O, tmp_path):
     sol, rn, _ = O.multigrid(f, np.zeros((M, M), order="F"), h, 5, 2, 2, 0.6, 4, coarse_exact=True)
     assert np.allclose(res["ResNorms"].ravel(), rn, rtol=1e-6, atol=1e-9 * rn[0])
     assert np.abs(res["Sol"] - sol).max() <= 1e-9 * np.abs(sol).max()
+
+
+def test_hostile_dimensions_in_the_file_are_refused(tmp_path):
+    """A MAT-v4 header whose dimensions are negative or promise more data than the file holds
+    must not reach an allocation or a wrapped size: the variable is not accepted."""
+    import struct
+    for mrows, ncols in ((-5, 5), (5, -5), (2 ** 31 - 1, 2 ** 31 - 1), (65536, 65536), (5, 5)):
+        body = struct.pack("<5i", 0, mrows, ncols, 0, 2) + b"f\0" + b"\0" * 64  # 8 doubles of data at most
+        (tmp_path / "Input.mat").write_bytes(body)
+        rc, out = run(["-v", "1"], tmp_path)
+        assert rc == 1 and ("do not fit the file" in out or "no variable f" in out), (mrows, ncols, out)

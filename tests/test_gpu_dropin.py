@@ -52,6 +52,31 @@ def test_dtsource_binding_matches_oracle(O, tmp_path, M, nv, nd, nu, omega, coar
     assert_bits(own["ResNorms"].ravel(), res["ResNorms"].ravel(), "ResNorms, CLI vs DTSource binding")
 
 
+def test_dtsource_binding_over_several_slabs(O, tmp_path):
+    """The same binding with mgx_options.ngpus = 3: MultiGrid() as main.cpp:445 calls it, over
+    three j-slabs (sharing the box's GPU), Output.mat bit-identical to the oracle."""
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/dt_dropin not built (needs the reference checkout at build time)")
+    from multigrid_amd import rhs
+    M = 1025
+    h = 1.0 / (M - 1)
+    f = rhs.random_np(M)
+    mat4.write(tmp_path / "Input.mat", [("f", f), ("f_loc", np.array([[0.0, 0.0, h, h]]))])
+    rc, out = _run([BIN, 4, 2, 2, 0.6, 2, 3, 129], tmp_path)
+    assert rc == 0, out
+    res = mat4.read(tmp_path / "Output.mat")
+    sol, rn, _ = O.multigrid(f, np.zeros((M, M), order="F"), h, 4, 2, 2, 0.6, 2)
+    assert_bits(res["ResNorms"].ravel(), rn, "ResNorms")
+    assert_bits(res["Sol"], sol, "Sol")
+    # this build's command-line driver with --ngpus
+    os.rename(tmp_path / "Output.mat", tmp_path / "Output_dt.mat")
+    rc, out = _run([CLI, "-v", 4, "-b", 2, "-a", 2, "--ngpus", 3, "--tail-m", 129], tmp_path)
+    assert rc == 0, out
+    own = mat4.read(tmp_path / "Output.mat")
+    assert_bits(own["Sol"], sol, "Sol, CLI --ngpus")
+    assert_bits(own["ResNorms"].ravel(), rn, "ResNorms, CLI --ngpus")
+
+
 def test_dtsource_binding_reports_errors_like_the_reference(tmp_path):
     if not os.path.exists(BIN):
         pytest.skip("oracle/_ref/dt_dropin not built")

@@ -140,7 +140,6 @@ def test_16385_partitioned_equals_the_single_plan(mg, R):
         a = s.own_first - s.col_first
         own = v[a:a + s.own_count]
         assert torch.equal(own.view(torch.int64), want.t()[s.own_first:s.own_first + s.own_count].view(torch.int64))
-    x, g, _ = P.stats()
     P.close()
     plan.close()
 
@@ -153,6 +152,6 @@ def test_exchange_and_gather_counts(mg):
     P.set_random_rhs()
     P.profile(True)
     P.cycles(5, 2, 2, 0.6)
-    x, g, host = P.stats()
-    assert g == 5 and x == 1 + 5 + 1 and host > 0
+    x, g, host, enq = P.stats()
+    assert g == 5 and x == 1 + 5 + 1 and 0 < enq <= host
     P.close()
