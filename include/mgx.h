@@ -50,8 +50,18 @@ typedef struct mgx_options {
                          (mgx_mplan_*, below).  A grid too small to split runs on one device.   */
     int tail_m;       /* partitioned runs: largest level (points per side) that every slab
                          holds whole instead of a share of; 0 = default (1025, MGX_TAIL_M)      */
-    int reserved[5];
+    int flags;        /* MGX_FLAG_* bits, see below                                             */
+    int reserved[4];
 } mgx_options;
+
+/* options.flags
+ *   MGX_FLAG_ZERO_GUESS  mgx_solve2d: the caller states that every INTERIOR entry of v is
+ *                        +0.0 (what main.cpp:420-421 passes: u = 0, then the boundary is
+ *                        filled).  Only the boundary of v is then read from the host array,
+ *                        which saves one of the three host<->device transfers of the call.
+ *                        The result is the same bits; a wrong statement gives the solution
+ *                        for the zero guess. */
+#define MGX_FLAG_ZERO_GUESS 1
 
 #define MGX_SCHEDULE_DEFAULT 0
 #define MGX_SCHEDULE_STEPWISE 1
@@ -141,8 +151,13 @@ int mgx_plan_commit(mgx_plan *plan);
 int mgx_plan_set_dev(mgx_plan *plan, const double *f_dev, const double *v_dev);
 int mgx_plan_get_dev(mgx_plan *plan, double *v_dev);
 
-/* Host <-> plan copies (synchronous with respect to the plan's stream). */
+/* Host <-> plan copies (synchronous with respect to the plan's stream).  The arrays may be
+ * ordinary pageable memory (what DTMutableDoubleArray holds, DTDoubleArray.cpp:39): big ones
+ * move through pinned staging buffers on several host threads (MGX_IO_THREADS, default 8),
+ * which about doubles the rate of a plain hipMemcpy.  upload_boundary sets the iterate to
+ * zero in the interior and to v_host on the four boundary lines (all it reads of v_host). */
 int mgx_plan_upload(mgx_plan *plan, const double *f_host, const double *v_host);
+int mgx_plan_upload_boundary(mgx_plan *plan, const double *v_host);
 int mgx_plan_download(mgx_plan *plan, double *v_host);
 
 /* Nv V(Ndown,Nup) cycles on the resident data; the V-cycle loop of

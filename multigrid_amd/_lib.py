@@ -30,7 +30,8 @@ class mgx_options(ctypes.Structure):
         ("coarse_solve", ctypes.c_int),
         ("ngpus", ctypes.c_int),
         ("tail_m", ctypes.c_int),
-        ("reserved", ctypes.c_int * 5),
+        ("flags", ctypes.c_int),
+        ("reserved", ctypes.c_int * 4),
     ]
 
 
@@ -91,6 +92,7 @@ SIGNATURES = {
     "mgx_plan_set_dev": (ctypes.c_int, [_vp, _vp, _vp]),
     "mgx_plan_get_dev": (ctypes.c_int, [_vp, _vp]),
     "mgx_plan_upload": (ctypes.c_int, [_vp, _vp, _vp]),
+    "mgx_plan_upload_boundary": (ctypes.c_int, [_vp, _vp]),
     "mgx_plan_download": (ctypes.c_int, [_vp, _vp]),
     "mgx_plan_cycles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_int, _vp, _vp]),
@@ -166,7 +168,11 @@ def check(rc):
     return rc
 
 
-def make_options(device=-1, stream=None, schedule=SCHEDULE_DEFAULT, verbose=0, coarse_solve=0, ngpus=0, tail_m=0):
+FLAG_ZERO_GUESS = 1
+
+
+def make_options(device=-1, stream=None, schedule=SCHEDULE_DEFAULT, verbose=0, coarse_solve=0, ngpus=0, tail_m=0,
+                 flags=0):
     o = mgx_options()
     o.struct_size = ctypes.sizeof(mgx_options)
     o.device = device
@@ -176,4 +182,5 @@ def make_options(device=-1, stream=None, schedule=SCHEDULE_DEFAULT, verbose=0, c
     o.coarse_solve = coarse_solve
     o.ngpus = ngpus
     o.tail_m = tail_m
+    o.flags = flags
     return o

@@ -745,12 +745,38 @@ int mgx_plan_upload(mgx_plan *p, const double *f_host, const double *v_host)
     DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_upload: null plan");
     Level &L = p->lv[0];
-    const size_t nb = sizeof(double) * L.n();
-    if (f_host) HIP_TRY(hipMemcpyAsync(L.f, f_host, nb, hipMemcpyHostToDevice, p->stream));
-    if (v_host) HIP_TRY(hipMemcpyAsync(L.v[0], v_host, nb, hipMemcpyHostToDevice, p->stream));
+    if (f_host) HIP_TRY(host_to_device(L.f, f_host, L.n(), p->stream));
+    if (v_host) HIP_TRY(host_to_device(L.v[0], v_host, L.n(), p->stream));
     int rc = mgx_plan_commit(p);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(p->stream));
+    return MGX_OK;
+}
+
+int mgx_plan_upload_boundary(mgx_plan *p, const double *v_host)
+{
+    DeviceScope on_plan_device(p);
+    if (!p || !v_host) return fail(MGX_ERR_ARG, "mgx_plan_upload_boundary: null argument");
+    Level &L = p->lv[0];
+    const size_t m = (size_t)L.m, col = sizeof(double) * m;
+    hipStream_t s = p->stream;
+    HIP_TRY(hipMemsetAsync(L.v[0], 0, sizeof(double) * L.n(), s));
+    // columns 0 and m-1 are contiguous; rows 0 and m-1 are one double per column
+    HIP_TRY(hipMemcpyAsync(L.v[0], v_host, col, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(L.v[0] + (m - 1) * m, v_host + (m - 1) * m, col, hipMemcpyHostToDevice, s));
+    // (a strided copy straight from pageable memory takes ~130 ms per row at 16385: gather on
+    // the host, one small upload into the idle residual scratch, scatter with a kernel)
+    std::vector<double> rows(2 * m);
+    for (size_t j = 0; j < m; j++) {
+        rows[j] = v_host[j * m];
+        rows[m + j] = v_host[j * m + (m - 1)];
+    }
+    HIP_TRY(hipMemcpyAsync(p->r, rows.data(), sizeof(double) * 2 * m, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // `rows` is about to go out of scope
+    HIP_TRY(launch_set_boundary_rows(L.v[0], L.m, p->r, s));
+    int rc = mgx_plan_commit(p);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
     return MGX_OK;
 }
 
@@ -759,8 +785,7 @@ int mgx_plan_download(mgx_plan *p, double *v_host)
     DeviceScope on_plan_device(p);
     if (!p || !v_host) return fail(MGX_ERR_ARG, "mgx_plan_download: null argument");
     Level &L = p->lv[0];
-    HIP_TRY(hipMemcpyAsync(v_host, L.v[0], sizeof(double) * L.n(), hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(device_to_host(v_host, L.v[0], L.n(), p->stream));
     return MGX_OK;
 }
 
@@ -1000,7 +1025,12 @@ int mgx_solve2d(const double *f, double *v, int m, int n, double dx,
     mgx_plan *p = nullptr;
     int rc = mgx_plan_create(&p, m, dx, coarsest, opt);
     if (rc) return rc;
-    rc = mgx_plan_upload(p, f, v);
+    if (opt && opt->struct_size == (int)sizeof(mgx_options) && (opt->flags & MGX_FLAG_ZERO_GUESS)) {
+        rc = mgx_plan_upload(p, f, nullptr);  // the interior of v is zero by the caller's word: not read
+        if (!rc) rc = mgx_plan_upload_boundary(p, v);
+    } else {
+        rc = mgx_plan_upload(p, f, v);
+    }
     if (!rc) rc = mgx_plan_cycles(p, Nv, Ndown, Nup, omega, pure_jacobi, resnorms, times);
     if (!rc) rc = mgx_plan_download(p, v);
     mgx_plan_destroy(p);

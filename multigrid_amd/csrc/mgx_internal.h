@@ -88,11 +88,18 @@ hipError_t launch_direct3x3(double *v, const double *f, double h2, hipStream_t s
 hipError_t launch_boundary_plus_zero(double *v, int m, hipStream_t s);
 // the same for a slab of ncols columns; jfix_lo / jfix_hi: local physical boundary columns or -1
 hipError_t launch_slab_boundary_plus_zero(double *v, int m, int ncols, int jfix_lo, int jfix_hi, hipStream_t s);
+// rows 0 and m-1 of an m x m grid <- rows[0..m) and rows[m..2m) (device arrays)
+hipError_t launch_set_boundary_rows(double *v, int m, const double *rows, hipStream_t s);
 // full multigrid: coarse boundary point k <- fine boundary point 2k (all four sides)
 hipError_t launch_inject_boundary(const double *fine, int mf, double *coarse, int mc, hipStream_t s);
 hipError_t launch_norminf(const double *a, size_t len, unsigned long long *slot, hipStream_t s);
 hipError_t launch_residual_norm(const double *u, const double *f, int m, int jlo, int jhi, const SweepCoef &c,
                                 unsigned long long *slot, hipStream_t s);
+
+// ---- ordinary (pageable) host arrays <-> device, several threads through pinned staging
+// buffers (mgx_hostio.hip).  Synchronous; work already enqueued on `order` comes first.
+hipError_t host_to_device(double *dst_dev, const double *src_host, size_t count, hipStream_t order);
+hipError_t device_to_host(double *dst_host, const double *src_dev, size_t count, hipStream_t order);
 
 // ---- the LDS-resident bottom of the cycle (mgx_tail.hip) -----------------------
 static constexpr int TAIL_MAX_M = 65;

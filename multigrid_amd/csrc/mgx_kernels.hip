@@ -245,6 +245,21 @@ hipError_t launch_slab_boundary_plus_zero(double *v, int m, int ncols, int jfix_
     return hipGetLastError();
 }
 
+// rows 0 and m-1 of an m x m grid from two contiguous arrays (rows[0..m) and rows[m..2m))
+__global__ void k_set_boundary_rows(double *__restrict__ v, int m, const double *__restrict__ rows)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    v[(size_t)j * (size_t)m] = rows[j];
+    v[(size_t)j * (size_t)m + (size_t)(m - 1)] = rows[(size_t)m + j];
+}
+
+hipError_t launch_set_boundary_rows(double *v, int m, const double *rows, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_set_boundary_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, v, m, rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_inject_boundary(const double *fine, int mf, double *coarse, int mc, hipStream_t s)
 {
     hipLaunchKernelGGL(k_inject_boundary, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, s, fine, mf, coarse, mc);

@@ -175,6 +175,7 @@ int main(int argc, const char *argv[])
     opt.coarse_solve = a.exact_coarse ? MGX_COARSE_EXACT : MGX_COARSE_REFERENCE;
     opt.ngpus = a.ngpus;
     opt.tail_m = a.tail_m;
+    opt.flags = MGX_FLAG_ZERO_GUESS;  // u is zero apart from its boundary (main.cpp:420-439)
     rc = mgx_solve2d(f.data(), u.data(), M, N, dx, a.Nv, a.Ndown, a.Nup, a.omega, a.coarsest, 0, resnorm.data(),
                      times.data(), &opt);  // main.cpp:445
     if (rc != MGX_OK) {

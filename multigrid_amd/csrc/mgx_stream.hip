@@ -153,21 +153,46 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
     const double *__restrict__ pfb = A.f + rb_c;
     double *__restrict__ po = A.uout + ra;
 
+#ifndef MGX_NT_LOAD
+#define MGX_NT_LOAD 0
+#endif
+// The iterate is written once per launch and read again a whole launch later (2 GB at
+// 16385^2): a non-temporal store keeps it from displacing the halo rows and columns that
+// neighbouring waves still share through the L2 (level-0 up+down launch 1.570 -> 1.554 ms).
+// Non-temporal LOADS of the streamed arrays lose (1.64 ms): they give up exactly that sharing.
+#ifndef MGX_NT_STORE
+#define MGX_NT_STORE 1
+#endif
     auto load_col = [&](const double *__restrict__ pa, const double *__restrict__ pb, int j) -> P2 {
         const size_t off = (size_t)clampi(j, 0, ncols - 1) * ld;
         P2 r;
+#if MGX_NT_LOAD
+        r.a = __builtin_nontemporal_load(pa + off);
+        r.b = __builtin_nontemporal_load(pb + off);
+#else
         r.a = pa[off];
         r.b = pb[off];  // adjacent to r.a on interior strips: one 16-byte load
+#endif
         return r;
     };
     auto store_col = [&](int j, const P2 &v) {
         if (EDGE) {
+#if MGX_NT_STORE
+            if (owna) __builtin_nontemporal_store(v.a, po + (size_t)j * ld);
+            if (ownb) __builtin_nontemporal_store(v.b, po + (size_t)j * ld + 1);
+#else
             if (owna) po[(size_t)j * ld] = v.a;
             if (ownb) po[(size_t)j * ld + 1] = v.b;
+#endif
         } else if (owna) {
             double *q = po + (size_t)j * ld;
+#if MGX_NT_STORE
+            __builtin_nontemporal_store(v.a, q);
+            __builtin_nontemporal_store(v.b, q + 1);
+#else
             q[0] = v.a;
             q[1] = v.b;
+#endif
         }
     };
 

@@ -466,12 +466,13 @@ def MultiGrid(prob, Nv, Ndown, Nup, omega, coarsest, pureJacobi=False, schedule=
 
 
 def solve_host(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pureJacobi=False, schedule=_lib.SCHEDULE_DEFAULT,
-               coarse_solve=_lib.COARSE_REFERENCE, ngpus=0, tail_m=0):
+               coarse_solve=_lib.COARSE_REFERENCE, ngpus=0, tail_m=0, zero_guess=False):
     """mgx_solve2d on host numpy arrays (the drop-in for main.cpp:445).
 
     f, v: Fortran-ordered float64 m x n; v is overwritten.  Returns MGOutputs.  ngpus > 1 splits
     the grid into that many j-slabs (mgx_options.ngpus), tail_m sets the largest level every
-    slab holds whole."""
+    slab holds whole; zero_guess=True states that the interior of v is zero (only its boundary
+    is then uploaded)."""
     f = np.asfortranarray(f, dtype=np.float64)
     if not (isinstance(v, np.ndarray) and v.dtype == np.float64 and v.flags.f_contiguous):
         raise TypeError("v must be a Fortran-ordered float64 numpy array (it is written in place)")
@@ -481,7 +482,8 @@ def solve_host(f, v, dx, Nv, Ndown, Nup, omega, coarsest=2, pureJacobi=False, sc
     res = np.zeros(Nv + 1)
     tim = np.zeros(Nv + 1)
     L = _lib.load()
-    opt = _lib.make_options(schedule=schedule, coarse_solve=coarse_solve, ngpus=ngpus, tail_m=tail_m)
+    opt = _lib.make_options(schedule=schedule, coarse_solve=coarse_solve, ngpus=ngpus, tail_m=tail_m,
+                            flags=_lib.FLAG_ZERO_GUESS if zero_guess else 0)
     _lib.check(L.mgx_solve2d(f.ctypes.data, v.ctypes.data, m, n, dx, Nv, Ndown, Nup, omega, coarsest,
                              int(bool(pureJacobi)), res.ctypes.data, tim.ctypes.data, ctypes.byref(opt)))
     return MGOutputs(res, tim)

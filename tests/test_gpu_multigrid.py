@@ -275,3 +275,29 @@ def test_schedules_agree_at_large_sizes_that_are_not_powers_of_two(mg, k, d):
         res.append((out.ResidualNorms, prob.v))
     assert_bits(res[0][0], res[1][0], "ResNorms m=%d" % m)
     assert torch.equal(res[0][1].view(torch.int64), res[1][1].view(torch.int64))
+
+
+def test_host_arrays_through_the_staged_transfers(mg, O):
+    """mgx_solve2d on ordinary host arrays big enough (134 MB each) for the multi-threaded
+    staged upload/download, with a non-zero guess and Dirichlet data: same bits as the oracle;
+    with the zero-guess flag only the boundary of v is read."""
+    from multigrid_amd import rhs
+    m = 4097
+    dx = 1.0 / (m - 1)
+    f = rhs.random_np(m)
+    rng = np.random.default_rng(5)
+    v0 = np.asfortranarray(rng.standard_normal((m, m)) * 0.01)
+    sol, rn, _ = O.multigrid(f, v0, dx, 2, 2, 2, 0.6, 2, omp=True)
+    v = v0.copy(order="F")
+    out = mg.solve_host(f, v, dx, 2, 2, 2, 0.6, 2)
+    assert_bits(out.ResidualNorms, rn, "ResNorms")
+    assert_bits(v, sol, "Sol")
+    # zero guess stated: the interior of v is not read (garbage there must not matter)
+    vz = np.zeros((m, m), order="F")
+    vz[0, :], vz[-1, :], vz[:, 0], vz[:, -1] = rng.standard_normal((4, m))
+    sol, rn, _ = O.multigrid(f, vz, dx, 2, 2, 2, 0.6, 2, omp=True)
+    v = vz.copy(order="F")
+    v[1:-1, 1:-1] = 123.0
+    out = mg.solve_host(f, v, dx, 2, 2, 2, 0.6, 2, zero_guess=True)
+    assert_bits(out.ResidualNorms, rn, "ResNorms, zero guess")
+    assert_bits(v, sol, "Sol, zero guess")
