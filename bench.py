@@ -140,6 +140,10 @@ def main():
     ap.add_argument("--omega", type=float, default=0.6)
     ap.add_argument("--schedule", type=int, default=0, help="0 default, 1 stepwise, 2 fused")
     ap.add_argument("--slab", action="store_true", help="run the j-slab driver even on one GPU")
+    ap.add_argument("--mplan", type=int, default=0,
+                    help="single process: the partitioned plan in C++ (mgx_mplan_*) over this many slabs, slab k on "
+                         "device k modulo the visible devices (a rehearsal on one GPU: every slab's copy of the "
+                         "tail then runs on that GPU)")
     ap.add_argument("--tail-m", type=int, default=0,
                     help="slab driver: largest replicated (tail) level size; 0 = 2049 on one rank, 1025 on more")
     ap.add_argument("--coarsest", type=int, default=2, help="the reference's -c (threshold for the direct solver)")
@@ -189,7 +193,13 @@ def main():
     dx = 1.0 / (M - 1)
     coarse_solve = mg.COARSE_EXACT if args.exact_coarse else mg.COARSE_REFERENCE
 
-    if world == 1 and not args.slab:
+    if world == 1 and args.mplan > 0:
+        solver = mg.MultiPlan(M, dx, args.coarsest, nslabs=args.mplan, tail_m=args.tail_m, coarse_solve=coarse_solve)
+        solver.set_random_rhs()
+        depth = solver.depth
+        schedule_name = "one process, %d j-slabs on %d device(s), %d distributed levels, replicated tail from %d^2" % (
+            args.mplan, min(args.mplan, ndev), solver.ndist, solver.tail_m)
+    elif world == 1 and not args.slab:
         plan = mg.Plan(M, dx, args.coarsest, schedule=args.schedule, coarse_solve=coarse_solve)
         plan.set(rhs.random_torch(M), mg.colmajor(M, M))
         solver = plan

@@ -93,3 +93,58 @@ def test_slab_launch_rejects_missing_halo(mg):
     assert b"halo columns needed" in L.mgx_last_error()
     o.jlo, o.jhi = 2, 18
     assert L.mgx_slab_launch(ctypes.byref(o), None) == 0
+
+
+def test_slab_solver_under_a_stream_other_than_the_one_it_was_built_on(mg, O):
+    """The tail plan follows torch's CURRENT stream at every call (mgx_plan_set_stream): a
+    solver built on the default stream and run inside `torch.cuda.stream(side)` orders its
+    tail after the gather that fills the tail's right-hand side and before the up leg that
+    reads the tail's iterate -- same bits as the oracle, on either stream, back and forth."""
+    import torch
+    from multigrid_amd import rhs, slab
+    M = 1025
+    dx = 1.0 / (M - 1)
+    f = rhs.random_np(M)
+    v0 = np.zeros((M, M), order="F")
+    ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, 6, 2, 2, 0.6, 2)
+    S = slab.SlabSolver(M, dx, 2, tail_m=129)      # built on the default stream
+    S.set_problem(f, v0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        a = S.cycles(2, 2, 2, 0.6)
+    torch.cuda.current_stream().wait_stream(side)
+    b = S.cycles(2, 2, 2, 0.6)                     # back on the default stream
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        c = S.cycles(2, 2, 2, 0.6)
+        sol = S.gather_solution()
+    side.synchronize()
+    S.close()
+    rn = np.concatenate([a.ResidualNorms, b.ResidualNorms[1:], c.ResidualNorms[1:]])
+    assert_bits(rn, ref_rn, "ResNorms across streams")
+    assert_bits(sol, ref_sol, "Sol across streams")
+
+
+def test_plan_follows_the_current_stream(mg, O):
+    """solver.Plan built on one stream, used under another (Plan.set/cycles/get call
+    mgx_plan_set_stream with the stream that is current)."""
+    import torch
+    from multigrid_amd import rhs
+    m = 513
+    dx = 1.0 / (m - 1)
+    f = rhs.random_np(m)
+    sol, rn, _ = O.multigrid(f, np.zeros((m, m), order="F"), dx, 4, 2, 2, 0.6, 2)
+    plan = mg.Plan(m, dx, 2)
+    fd = mg.to_device(f)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.set(fd, mg.colmajor(m, m))
+        a = plan.cycles(2, 2, 2, 0.6)
+    b = plan.cycles(2, 2, 2, 0.6)   # default stream again: ordered after the side stream's work
+    got = plan.get()
+    torch.cuda.synchronize()
+    assert_bits(np.concatenate([a.ResidualNorms, b.ResidualNorms[1:]]), rn, "ResNorms")
+    assert_bits(mg.to_numpy(got), sol, "Sol")
+    plan.close()
