@@ -200,13 +200,30 @@ int slab_fail(Slab &S, int code, const char *fmt, ...)
         if (rc_ != MGX_OK) return rc_; \
     } while (0)
 
-// wait (on the host) until a neighbour's counter reaches x; gives up when any slab failed
+// wait (on the host) until a neighbour's counter reaches x; gives up when any slab failed,
+// or after MGX_MPLAN_TIMEOUT seconds (default 120): the slabs then disagree about the number
+// of hand-shakes of the schedule, which is a bug here and must not hang the caller
 bool spin_until(mgx_mplan *mp, const std::atomic<long> &c, long x)
 {
-    int n = 0;
+    static const double limit = [] {
+        const char *e = getenv("MGX_MPLAN_TIMEOUT");
+        const double v = e ? atof(e) : 120.0;
+        return v > 0 ? v : 120.0;
+    }();
+    long n = 0;
+    timespec t0 = {0, 0};
     while (c.load(std::memory_order_acquire) < x) {
         if (mp->failed.load(std::memory_order_acquire)) return false;
         if (++n > 64) std::this_thread::yield();
+        if ((n & 0xfff) == 0) {
+            timespec t;
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            if (t0.tv_sec == 0) t0 = t;
+            if ((double)(t.tv_sec - t0.tv_sec) > limit) {
+                mp->failed.store(2, std::memory_order_release);
+                return false;
+            }
+        }
     }
     return true;
 }
@@ -567,7 +584,9 @@ int launch_level0(Slab &S, int kid, OpSpec o, const std::vector<XItem> &items, b
     }
     o.jlo = ilo;
     o.jhi = ihi;
-    if (split) {
+    // (whether a slab splits its launch depends on its own width, so the number of exchanges
+    // must not depend on the split: nothing to exchange means no exchange on either path)
+    if (split && !items.empty()) {
         if (flip) L.cur ^= 1;  // from here on v[cur] is the buffer being written
         S_TRY(exchange_begin(S, items));
         S_TRY(launch(S, 0, kid, o));
@@ -841,8 +860,10 @@ int on_every_slab(mgx_mplan *mp, F fn)
             return api_fail(rc, "%s", msg.c_str());
         }
     if (mp->failed.load()) {
+        const int why = mp->failed.load();
         mp->failed.store(0);
-        return api_fail(MGX_ERR_STATE, "a slab thread gave up");
+        return api_fail(MGX_ERR_STATE, why == 2 ? "a slab's hand-shake with its neighbour timed out (MGX_MPLAN_TIMEOUT)"
+                                                : "a slab thread gave up");
     }
     return MGX_OK;
 }

@@ -32,6 +32,10 @@ while time.time() < t_end:
     v0 = np.asfortranarray(rng.standard_normal((M, M)) * float(rng.choice([0.0, 1.0])))
     dx = float(rng.choice([1.0, 1.0 / (M - 1), 0.37]))
     mode = int(rng.integers(0, 10))
+    if os.environ.get("FUZZ_LOG"):  # one line per case, so that a hang names its case
+        with open(os.environ["FUZZ_LOG"], "a") as fh:
+            fh.write("case %d: %r\n" % (n, dict(M=M, coarsest=coarsest, nd=nd, nu=nu, omega=omega, Nv=Nv, sched=sched,
+                                                pj=pj, dx=dx, mode=mode)))
     if mode == 0 and not pj:  # full multigrid
         try:
             sol, rn = O.fmg(f, v0, dx, Nv, nd, nu, omega, coarsest)
@@ -70,6 +74,35 @@ while time.time() < t_end:
                 np.array_equal(np.ascontiguousarray(v).view(np.uint64), np.ascontiguousarray(sol).view(np.uint64))):
             print("SLAB MISMATCH", dict(M=M, coarsest=coarsest, nd=nd, nu=nu, omega=omega, Nv=Nv, sched=sched, pj=pj, dx=dx,
                                         tail_m=tail_m, fmg=use_fmg, ndist=S.ndist))
+            sys.exit(1)
+        continue
+    if mode in (3, 4) and M >= 65:  # the partitioned plan in one process: random slab count, split calls
+        R = int(rng.integers(1, 9))
+        tail_m = int(rng.choice([17, 33, 65, 129]))
+        try:
+            sol, rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, coarsest, pure_jacobi=pj)
+        except ValueError:
+            continue
+        try:
+            P = mg.MultiPlan(M, dx, coarsest, nslabs=R, devices=[0] * R, tail_m=tail_m)
+        except mg.MgxError:
+            continue  # too few columns per slab
+        P.upload(f, v0)
+        k1 = int(rng.integers(0, Nv + 1))
+        if os.environ.get("FUZZ_LOG"):
+            with open(os.environ["FUZZ_LOG"], "a") as fh:
+                fh.write("   mplan R=%d tail_m=%d k1=%d ndist=%d\n" % (R, tail_m, k1, P.ndist))
+        a = P.cycles(k1, nd, nu, omega, pureJacobi=pj)
+        b = P.cycles(Nv - k1, nd, nu, omega, pureJacobi=pj)
+        v = P.download()
+        ndist = P.ndist
+        P.close()
+        got = np.concatenate([a.ResidualNorms, b.ResidualNorms[1:]])
+        n += 1
+        if not (np.array_equal(got.view(np.uint64), rn.view(np.uint64)) and
+                np.array_equal(v.view(np.uint64), sol.view(np.uint64))):
+            print("MPLAN MISMATCH", dict(M=M, coarsest=coarsest, nd=nd, nu=nu, omega=omega, Nv=Nv, k1=k1, pj=pj, dx=dx,
+                                         tail_m=tail_m, R=R, ndist=ndist))
             sys.exit(1)
         continue
     if mode == 2 and not pj:  # the exact coarsest solve (an extension): agreement to rounding, not bitwise
