@@ -386,6 +386,13 @@ int mgx_mplan_commit(mgx_mplan *plan);
  * mgx_plan_cycles (times: whole-cycle device time of slab 0).  Synchronous. */
 int mgx_mplan_cycles(mgx_mplan *plan, int Nv, int Ndown, int Nup, double omega, int pure_jacobi, double *resnorms,
                      double *times);
+/* EXTENSION: full multigrid over the slabs, the composition mgx_plan_fmg() runs on one
+ * device (same arguments, same bits): right-hand side restricted to every level, Dirichlet
+ * values injected, every slab's tail runs its own mgx_plan_fmg, each distributed level then
+ * starts from refine() of the level below and runs ncyc V(Ndown,Nup) cycles on the hierarchy
+ * below it.  Only the boundary values of v are read.  resnorms/times: the finest level's
+ * history (ncyc+1 entries each, or NULL). */
+int mgx_mplan_fmg(mgx_mplan *plan, int ncyc, int Ndown, int Nup, double omega, double *resnorms, double *times);
 /* Measure the launch shapes of every slab's big launches now (see mgx_plan_tune). */
 int mgx_mplan_tune(mgx_mplan *plan, int Ndown, int Nup, double omega);
 /* Per-launch timing of slab 0's level-0 launches (kernel ids as mgx_plan_profile; the

@@ -127,6 +127,7 @@ SIGNATURES = {
     "mgx_mplan_commit": (ctypes.c_int, [_vp]),
     "mgx_mplan_cycles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                         _vp, _vp]),
+    "mgx_mplan_fmg": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, _vp, _vp]),
     "mgx_mplan_tune": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     "mgx_mplan_profile": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mgx_mplan_profile_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_long),

@@ -88,6 +88,9 @@ hipError_t launch_direct3x3(double *v, const double *f, double h2, hipStream_t s
 hipError_t launch_boundary_plus_zero(double *v, int m, hipStream_t s);
 // the same for a slab of ncols columns; jfix_lo / jfix_hi: local physical boundary columns or -1
 hipError_t launch_slab_boundary_plus_zero(double *v, int m, int ncols, int jfix_lo, int jfix_hi, hipStream_t s);
+// full multigrid over slabs: Dirichlet values of n coarse columns (local row0..row0+n) from a fine slab
+hipError_t launch_slab_inject_boundary(const double *fine, int mf, int ncols_f, int fl0, double *coarse, int mc,
+                                       int row0, int n, int first, int last, hipStream_t s);
 // rows 0 and m-1 of an m x m grid <- rows[0..m) and rows[m..2m) (device arrays)
 hipError_t launch_set_boundary_rows(double *v, int m, const double *rows, hipStream_t s);
 // full multigrid: coarse boundary point k <- fine boundary point 2k (all four sides)

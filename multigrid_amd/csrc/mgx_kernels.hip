@@ -245,6 +245,36 @@ hipError_t launch_slab_boundary_plus_zero(double *v, int m, int ncols, int jfix_
     return hipGetLastError();
 }
 
+// Full multigrid over slabs: the Dirichlet values of n coarse columns (stored in `coarse`
+// from local column row0 on, mc rows) from the fine slab `fine` (mf rows, ncols_f columns):
+// coarse column row0+k pairs with fine local column fl0+2k; boundary point i of a coarse
+// boundary column pairs with fine point 2i.  `first` / `last`: the range starts / ends with
+// the physical boundary column (fine local column 0 / ncols_f-1), which is injected whole.
+__global__ void k_slab_inject_boundary(const double *__restrict__ fine, int mf, int ncols_f, int fl0,
+                                       double *__restrict__ coarse, int mc, int row0, int n, int first, int last)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t lf = (size_t)mf, lc = (size_t)mc;
+    if (k < n) {
+        coarse[(size_t)(row0 + k) * lc] = fine[(size_t)(fl0 + 2 * k) * lf];
+        coarse[(size_t)(row0 + k) * lc + (lc - 1)] = fine[(size_t)(fl0 + 2 * k) * lf + (lf - 1)];
+    }
+    if (k < mc) {
+        if (first) coarse[(size_t)row0 * lc + k] = fine[(size_t)(2 * k)];
+        if (last) coarse[(size_t)(row0 + n - 1) * lc + k] = fine[(size_t)(ncols_f - 1) * lf + (size_t)(2 * k)];
+    }
+}
+
+hipError_t launch_slab_inject_boundary(const double *fine, int mf, int ncols_f, int fl0, double *coarse, int mc,
+                                       int row0, int n, int first, int last, hipStream_t s)
+{
+    const int t = n > mc ? n : mc;
+    if (t <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_slab_inject_boundary, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, fine, mf, ncols_f, fl0,
+                       coarse, mc, row0, n, first, last);
+    return hipGetLastError();
+}
+
 // rows 0 and m-1 of an m x m grid from two contiguous arrays (rows[0..m) and rows[m..2m))
 __global__ void k_set_boundary_rows(double *__restrict__ v, int m, const double *__restrict__ rows)
 {

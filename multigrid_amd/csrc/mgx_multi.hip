@@ -115,6 +115,8 @@ struct CycleArgs {
     int Nv = 0, Ndown = 0, Nup = 0, pure_jacobi = 0;
     double omega = 0;
     bool tune = false;
+    bool fmg = false;
+    int top = 0;  // the cycles run on the hierarchy that starts at this distributed level (full multigrid)
 };
 
 } // namespace
@@ -138,7 +140,8 @@ struct Slab {
     long xcount = 0;              // exchanges begun
     long tcount = 0;              // tail gathers begun
     std::vector<XItem> pending;
-    std::vector<int> Ev, Ef;
+    std::vector<int> Ev, Ef;  // halo widths of the lean schedule, indexed from the view's top level
+    int top = 0;              // top level of the hierarchy the current call cycles on
     size_t bytes = 0;
     int rc = MGX_OK;
     std::string err;
@@ -286,7 +289,7 @@ int launch(Slab &S, int level, int kid, const OpSpec &o)
     op.gc0 = o.cs.gc0;
     op.dx = L.dx;
     op.omega = o.omega;
-    const bool prof = S.mp->profile && level == 0 && kid >= 0;
+    const bool prof = S.mp->profile && level == 0 && S.top == 0 && kid >= 0;
     hipEvent_t a = nullptr, b = nullptr;
     if (prof && (a = pool_event(S))) S_HIP(S, hipEventRecord(a, S.compute));
     const int rc = mgx_slab_launch(&op, S.compute);
@@ -392,39 +395,47 @@ int halo_exchange(Slab &S, const std::vector<XItem> &items)
 
 // ---- the tail ------------------------------------------------------------------------------
 
-// Gather the tail's right-hand side (every slab's own columns, from that slab's staging
-// array of this cycle's parity) into this slab's tail plan and run the tail.
-int run_tail(Slab &S, const CycleArgs &a)
+// Gather an array of the tail's top level: every slab's own columns, from that slab's staging
+// array of this gather's parity, into `dst` (this slab's copy of the whole level).
+int gather_tail(Slab &S, double *dst)
 {
     mgx_mplan *mp = S.mp;
     const int nd = mp->nd, mt = mp->dims[nd];
-    if (mp->R > 1) {
-        const long t = ++S.tcount;
-        if (S.rank == 0) mp->ngathers++;
-        S_HIP(S, hipEventRecord(S.tready[t & 1], S.compute));
-        mp->tposted[S.rank].store(t, std::memory_order_release);
-        const std::vector<int> &tb = mp->bounds[nd];
-        for (int q = 0; q < mp->R; q++) {
-            const int k = (S.rank + q) % mp->R;  // own columns first, then round the ring
-            Slab &P = *mp->slabs[k];
-            const size_t off = (size_t)tb[k] * mt, bytes = sizeof(double) * (size_t)(tb[k + 1] - tb[k]) * mt;
-            if (k != S.rank) {
-                if (!spin_until(mp, mp->tposted[k], t)) return MGX_ERR_STATE;
-                S_HIP(S, hipStreamWaitEvent(S.compute, P.tready[t & 1], 0));
-            }
-            S_HIP(S, hipMemcpyPeerAsync(S.tail_f + off, S.dev, P.tailsrc[t & 1] + off, P.dev, bytes, S.compute));
+    if (mp->R == 1) return MGX_OK;  // the single slab writes the tail's arrays directly
+    const long t = ++S.tcount;
+    if (S.rank == 0) mp->ngathers++;
+    S_HIP(S, hipEventRecord(S.tready[t & 1], S.compute));
+    mp->tposted[S.rank].store(t, std::memory_order_release);
+    const std::vector<int> &tb = mp->bounds[nd];
+    for (int q = 0; q < mp->R; q++) {
+        const int k = (S.rank + q) % mp->R;  // own columns first, then round the ring
+        Slab &P = *mp->slabs[k];
+        const size_t off = (size_t)tb[k] * mt, bytes = sizeof(double) * (size_t)(tb[k + 1] - tb[k]) * mt;
+        if (k != S.rank) {
+            if (!spin_until(mp, mp->tposted[k], t)) return MGX_ERR_STATE;
+            S_HIP(S, hipStreamWaitEvent(S.compute, P.tready[t & 1], 0));
         }
+        S_HIP(S, hipMemcpyPeerAsync(dst + off, S.dev, P.tailsrc[t & 1] + off, P.dev, bytes, S.compute));
     }
+    return MGX_OK;
+}
+
+// Gather the tail's right-hand side and run one cycle of the tail from a zero iterate.
+int run_tail(Slab &S, const CycleArgs &a)
+{
+    S_TRY(gather_tail(S, S.tail_f));
     if (mgx_plan_vcycle_async(S.tail, a.Ndown, a.Nup, a.omega, 1) != MGX_OK)
         return slab_fail(S, MGX_ERR_STATE, "slab %d tail: %s", S.rank, mgx_last_error());
     return MGX_OK;
 }
 
-// where the last distributed level's down leg writes the tail's right-hand side this cycle
-double *tail_target(Slab &S)
+// where this slab puts its columns of a tail array for the NEXT gather: the staging array of
+// that gather's parity, or (a single slab) the tail's own array `direct`
+double *tail_staging(Slab &S, double *direct)
 {
-    return S.mp->R > 1 ? S.tailsrc[(S.tcount + 1) & 1] : S.tail_f;
+    return S.mp->R > 1 ? S.tailsrc[(S.tcount + 1) & 1] : direct;
 }
+double *tail_target(Slab &S) { return tail_staging(S, S.tail_f); }
 
 void coarse_of(Slab &S, int l, SLevel *&C, CoarseShape &cs)
 {
@@ -490,7 +501,7 @@ int chain(Slab &S, int level, int kid, int pro, int ns, int res, int zero_in, do
 
 int normalize_boundary(Slab &S)
 {
-    SLevel &L = S.lv[0];
+    SLevel &L = S.lv[S.top];
     for (int k = 0; k < 2; k++)
         S_HIP(S, launch_slab_boundary_plus_zero(L.v[k], L.m, L.ncols, L.jfix_lo, L.jfix_hi, S.compute));
     return MGX_OK;
@@ -500,15 +511,15 @@ int normalize_boundary(Slab &S)
 int cycle_general(Slab &S, const CycleArgs &a, unsigned long long *slot, bool first)
 {
     mgx_mplan *mp = S.mp;
-    const int nd = mp->nd;
-    for (int l = 0; l < nd; l++) {  // main.cpp:317-328
+    const int nd = mp->nd, top = a.top;
+    for (int l = top; l < nd; l++) {  // main.cpp:317-328
         SLevel &L = S.lv[l];
         SLevel *C;
         CoarseShape cs;
         coarse_of(S, l, C, cs);
         double *cf = C ? C->f : tail_target(S);
         std::vector<XItem> items;
-        if (l >= 1 && a.Ndown == 0) {  // the iterate is zero here: f -> coarse f, nothing stored
+        if (l > top && a.Ndown == 0) {  // the iterate is zero here: f -> coarse f, nothing stored
             OpSpec o;
             o.restrict_out = 1;
             o.zero_in = 1;
@@ -520,7 +531,7 @@ int cycle_general(Slab &S, const CycleArgs &a, unsigned long long *slot, bool fi
             S_TRY(fence_pulls(S));
             S_TRY(launch(S, l, MGX_KERNEL_FUSED_DOWN, o));
         } else {
-            S_TRY(chain(S, l, MGX_KERNEL_FUSED_DOWN, 0, a.Ndown, 1, l >= 1 ? 1 : 0, a.omega, cs, nullptr, cf, nullptr));
+            S_TRY(chain(S, l, MGX_KERNEL_FUSED_DOWN, 0, a.Ndown, 1, l > top ? 1 : 0, a.omega, cs, nullptr, cf, nullptr));
             items.push_back(XItem{l, false, L.W});
         }
         if (C) items.push_back(XItem{l + 1, true, C->W});
@@ -528,14 +539,14 @@ int cycle_general(Slab &S, const CycleArgs &a, unsigned long long *slot, bool fi
     }
     S_TRY(run_tail(S, a));
     if (first) S_TRY(normalize_boundary(S));
-    for (int l = nd - 1; l >= 0; l--) {  // main.cpp:335-346
+    for (int l = nd - 1; l >= top; l--) {  // main.cpp:335-346
         SLevel &L = S.lv[l];
         SLevel *C;
         CoarseShape cs;
         coarse_of(S, l, C, cs);
         const double *cv = C ? C->v[C->cur] : S.tail_v;
-        const int zero_in = (l >= 1 && a.Ndown == 0) ? 1 : 0;
-        const int res = (l == 0 && slot) ? 2 : 0;
+        const int zero_in = (l > top && a.Ndown == 0) ? 1 : 0;
+        const int res = (l == top && slot) ? 2 : 0;
         S_TRY(chain(S, l, MGX_KERNEL_FUSED_UP, 1, a.Nup, res, zero_in, a.omega, cs, cv, nullptr, slot));
         S_TRY(halo_exchange(S, {XItem{l, false, L.W}}));
     }
@@ -546,8 +557,8 @@ int cycle_general(Slab &S, const CycleArgs &a, unsigned long long *slot, bool fi
 std::vector<XItem> lean_items(Slab &S, bool with_v)
 {
     std::vector<XItem> items;
-    if (with_v) items.push_back(XItem{0, false, W0});
-    if (S.mp->nd >= 2) items.push_back(XItem{1, true, S.Ef[1]});
+    if (with_v) items.push_back(XItem{S.top, false, W0});
+    if (S.mp->nd - S.top >= 2) items.push_back(XItem{S.top + 1, true, S.Ef[1]});
     return items;
 }
 
@@ -557,10 +568,11 @@ std::vector<XItem> lean_items(Slab &S, bool with_v)
 int launch_level0(Slab &S, int kid, OpSpec o, const std::vector<XItem> &items, bool flip)
 {
     mgx_mplan *mp = S.mp;
-    SLevel &L = S.lv[0];
+    const int top = S.top;
+    SLevel &L = S.lv[top];
     int jlo, jhi;
     col_range(L, 0, -1, jlo, jhi);
-    const int ef1 = mp->nd >= 2 ? S.Ef[1] : 0;
+    const int ef1 = mp->nd - top >= 2 ? S.Ef[1] : 0;
     int B = std::max(2 * ef1, W0);
     B += B & 1;
     const bool lo_nb = L.lo > 0, hi_nb = L.hi < L.m;
@@ -572,13 +584,13 @@ int launch_level0(Slab &S, int kid, OpSpec o, const std::vector<XItem> &items, b
         if (lo_nb) {
             o.jlo = jlo;
             o.jhi = jlo + B;
-            S_TRY(launch(S, 0, -1, o));
+            S_TRY(launch(S, top, -1, o));
             ilo = jlo + B;
         }
         if (hi_nb) {
             o.jlo = jhi - B;
             o.jhi = jhi;
-            S_TRY(launch(S, 0, -1, o));
+            S_TRY(launch(S, top, -1, o));
             ihi = jhi - B;
         }
     }
@@ -589,10 +601,10 @@ int launch_level0(Slab &S, int kid, OpSpec o, const std::vector<XItem> &items, b
     if (split && !items.empty()) {
         if (flip) L.cur ^= 1;  // from here on v[cur] is the buffer being written
         S_TRY(exchange_begin(S, items));
-        S_TRY(launch(S, 0, kid, o));
+        S_TRY(launch(S, top, kid, o));
         return exchange_end(S);
     }
-    S_TRY(launch(S, 0, kid, o));
+    S_TRY(launch(S, top, kid, o));
     if (flip) L.cur ^= 1;
     if (!items.empty()) S_TRY(halo_exchange(S, items));
     return MGX_OK;
@@ -600,10 +612,10 @@ int launch_level0(Slab &S, int kid, OpSpec o, const std::vector<XItem> &items, b
 
 int lean_down0(Slab &S, const CycleArgs &a)
 {
-    SLevel &L = S.lv[0];
+    SLevel &L = S.lv[a.top];
     SLevel *C;
     CoarseShape cs;
-    coarse_of(S, 0, C, cs);
+    coarse_of(S, a.top, C, cs);
     OpSpec o;
     o.nsweeps = a.Ndown;
     o.restrict_out = 1;
@@ -620,8 +632,8 @@ int lean_down0(Slab &S, const CycleArgs &a)
 int lean_coarse(Slab &S, const CycleArgs &a)
 {
     mgx_mplan *mp = S.mp;
-    const int nd = mp->nd;
-    for (int l = 1; l < nd; l++) {
+    const int nd = mp->nd, top = a.top;
+    for (int l = top + 1; l < nd; l++) {
         SLevel &L = S.lv[l];
         SLevel *C;
         CoarseShape cs;
@@ -634,11 +646,11 @@ int lean_coarse(Slab &S, const CycleArgs &a)
         o.omega = a.omega;
         o.cs = cs;
         o.coarse_f = C ? C->f : tail_target(S);
-        col_range(L, 0, l + 1 < nd ? S.Ef[l + 1] : 0, o.jlo, o.jhi);
+        col_range(L, 0, l + 1 < nd ? S.Ef[l + 1 - top] : 0, o.jlo, o.jhi);
         S_TRY(launch(S, l, MGX_KERNEL_FUSED_DOWN, o));
     }
     S_TRY(run_tail(S, a));
-    for (int l = nd - 1; l >= 1; l--) {
+    for (int l = nd - 1; l > top; l--) {
         SLevel &L = S.lv[l];
         SLevel *C;
         CoarseShape cs;
@@ -652,7 +664,7 @@ int lean_coarse(Slab &S, const CycleArgs &a)
         o.v_out = L.v[0];
         o.cs = cs;
         o.coarse_v = C ? C->v[C->cur] : S.tail_v;
-        col_range(L, S.Ev[l], -1, o.jlo, o.jhi);
+        col_range(L, S.Ev[l - top], -1, o.jlo, o.jhi);
         L.cur = 0;
         S_TRY(launch(S, l, MGX_KERNEL_FUSED_UP, o));
     }
@@ -661,10 +673,10 @@ int lean_coarse(Slab &S, const CycleArgs &a)
 
 int lean_up0(Slab &S, const CycleArgs &a, unsigned long long *slot, bool next_down)
 {
-    SLevel &L = S.lv[0];
+    SLevel &L = S.lv[a.top];
     SLevel *C;
     CoarseShape cs;
-    coarse_of(S, 0, C, cs);
+    coarse_of(S, a.top, C, cs);
     OpSpec o;
     o.pro_stage = 0;
     o.norm_stage = a.Nup;
@@ -682,7 +694,7 @@ int lean_up0(Slab &S, const CycleArgs &a, unsigned long long *slot, bool next_do
         return launch_level0(S, MGX_KERNEL_FUSED_UPDOWN, o, lean_items(S, true), true);
     }
     o.nsweeps = a.Nup;
-    return launch_level0(S, MGX_KERNEL_FUSED_UP, o, {XItem{0, false, W0}}, true);
+    return launch_level0(S, MGX_KERNEL_FUSED_UP, o, {XItem{a.top, false, W0}}, true);
 }
 
 // Nv cycles on one slab (main.cpp:309-354): what each slab's thread runs.
@@ -690,6 +702,7 @@ int slab_cycles(Slab &S, const CycleArgs &a)
 {
     mgx_mplan *mp = S.mp;
     if (hipSetDevice(S.dev) != hipSuccess) return slab_fail(S, MGX_ERR_HIP, "slab %d: hipSetDevice(%d)", S.rank, S.dev);
+    S.top = a.top;
     const bool was_tune = set_tune_now(a.tune);
     struct Restore {
         bool was;
@@ -711,22 +724,22 @@ int slab_cycles(Slab &S, const CycleArgs &a)
         }
     const bool lean = !a.pure_jacobi && a.Ndown + a.Nup >= 1 && a.Ndown + a.Nup <= MAX_LEAN;
     if (lean) {
-        halo_plan(mp->nd, a.Ndown, a.Nup, S.Ev, S.Ef);
-        for (int l = 1; l < mp->nd; l++)
-            if (std::max(S.Ef[l], S.Ev[l]) > S.lv[l].W)
+        halo_plan(mp->nd - a.top, a.Ndown, a.Nup, S.Ev, S.Ef);
+        for (int l = a.top + 1; l < mp->nd; l++)
+            if (std::max(S.Ef[l - a.top], S.Ev[l - a.top]) > S.lv[l].W)
                 return slab_fail(S, MGX_ERR_STATE, "level %d halo %d exceeds the allocated %d", l,
-                                 std::max(S.Ef[l], S.Ev[l]), S.lv[l].W);
+                                 std::max(S.Ef[l - a.top], S.Ev[l - a.top]), S.lv[l].W);
     }
     const CoarseShape none;
     // main.cpp:307: the norm of the initial residual (halo columns of v must be current)
-    S_TRY(halo_exchange(S, {XItem{0, false, W0}}));
-    S_TRY(chain(S, 0, MGX_KERNEL_RESNORM, 0, 0, 2, 0, a.omega, none, nullptr, nullptr, S.slots + 0));
+    S_TRY(halo_exchange(S, {XItem{a.top, false, W0}}));
+    S_TRY(chain(S, a.top, MGX_KERNEL_RESNORM, 0, 0, 2, 0, a.omega, none, nullptr, nullptr, S.slots + 0));
     if (S.rank == 0) S_HIP(S, hipEventRecord(S.cyc[0], S.compute));
     for (int it = 0; it < Nv; it++) {
         unsigned long long *slot = S.slots + it + 1;
         if (a.pure_jacobi) {  // main.cpp:348 and :351 in one pass
-            S_TRY(chain(S, 0, MGX_KERNEL_FUSED_UP, 0, 1, 2, 0, a.omega, none, nullptr, nullptr, slot));
-            S_TRY(halo_exchange(S, {XItem{0, false, W0}}));
+            S_TRY(chain(S, a.top, MGX_KERNEL_FUSED_UP, 0, 1, 2, 0, a.omega, none, nullptr, nullptr, slot));
+            S_TRY(halo_exchange(S, {XItem{a.top, false, W0}}));
         } else if (lean) {
             if (it == 0) S_TRY(lean_down0(S, a));  // later cycles: the previous level-0 launch did the down leg
             S_TRY(lean_coarse(S, a));
@@ -736,6 +749,101 @@ int slab_cycles(Slab &S, const CycleArgs &a)
             S_TRY(cycle_general(S, a, slot, it == 0));
         }
         if (S.rank == 0) S_HIP(S, hipEventRecord(S.cyc[it + 1], S.compute));
+    }
+    return MGX_OK;
+}
+
+// EXTENSION (the reference has no full-multigrid driver): the composition mgx_plan_fmg runs
+// on one device, over the slabs.  The right-hand side is restricted to every level
+// (coarsen, main.cpp:201-221), the Dirichlet values of v are injected, every slab's tail runs
+// its own full multigrid (identical bits), and on the way up each distributed level starts
+// from refine() of the level below and runs a.Nv cycles on the hierarchy below it.  Only the
+// boundary values of v are used.
+int slab_fmg(Slab &S, const CycleArgs &a)
+{
+    mgx_mplan *mp = S.mp;
+    if (hipSetDevice(S.dev) != hipSuccess) return slab_fail(S, MGX_ERR_HIP, "slab %d: hipSetDevice(%d)", S.rank, S.dev);
+    const int nd = mp->nd, R = mp->R, g = S.rank, mt = mp->dims[nd];
+    const std::vector<int> &tb = mp->bounds[nd];
+    S.top = 0;
+    for (int l = 0; l < nd; l++) {
+        SLevel &L = S.lv[l];
+        SLevel *C;
+        CoarseShape cs;
+        coarse_of(S, l, C, cs);
+        // the residual of a zero iterate is the right-hand side itself: restriction of f
+        OpSpec o;
+        o.restrict_out = 1;
+        o.zero_in = 1;
+        o.store = 0;
+        o.omega = a.omega;
+        o.cs = cs;
+        const double *src = L.v[L.cur];
+        col_range(L, 0, -1, o.jlo, o.jhi);
+        if (!C) {
+            // The tail's iterate (its Dirichlet values) is gathered first, its right-hand side
+            // second: a staging array is written only after the gather that follows the one it
+            // was last read in (a peer may still be reading the array of the latest gather).
+            double *vstage = tail_staging(S, S.tail_v);
+            const size_t tbytes = sizeof(double) * (size_t)mt * mt;
+            S_HIP(S, hipMemsetAsync(S.tail_v, 0, tbytes, S.compute));
+            if (R > 1)
+                S_HIP(S, hipMemsetAsync(vstage + (size_t)tb[g] * mt, 0, sizeof(double) * (size_t)(tb[g + 1] - tb[g]) * mt,
+                                        S.compute));
+            S_HIP(S, launch_slab_inject_boundary(src, L.m, L.ncols, 2 * tb[g] - L.lo, vstage, mt, tb[g], tb[g + 1] - tb[g],
+                                                 g == 0, g == R - 1, S.compute));
+            S_TRY(gather_tail(S, S.tail_v));
+            o.coarse_f = tail_target(S);
+            S_TRY(launch(S, l, -1, o));
+            continue;
+        }
+        o.coarse_f = C->f;
+        S_TRY(fence_pulls(S));
+        S_TRY(launch(S, l, -1, o));
+        S_TRY(halo_exchange(S, {XItem{l + 1, true, C->W}}));
+        S_TRY(fence_pulls(S));
+        S_HIP(S, hipMemsetAsync(C->v[0], 0, C->bytes(), S.compute));
+        S_HIP(S, launch_slab_inject_boundary(src, L.m, L.ncols, 2 * C->b0 - L.lo, C->v[0], C->m, C->o0, C->b1 - C->b0,
+                                             C->lo == 0, C->hi == C->m, S.compute));
+        C->cur = 0;
+        S_TRY(halo_exchange(S, {XItem{l + 1, false, C->W}}));
+        S_HIP(S, hipMemcpyAsync(C->v[1], C->v[0], C->bytes(), hipMemcpyDeviceToDevice, S.compute));
+    }
+    S_TRY(gather_tail(S, S.tail_f));
+    if (mgx_plan_commit(S.tail) != MGX_OK ||
+        mgx_plan_fmg(S.tail, a.Nv, a.Ndown, a.Nup, a.omega, nullptr, nullptr) != MGX_OK)
+        return slab_fail(S, MGX_ERR_STATE, "slab %d tail full multigrid: %s", S.rank, mgx_last_error());
+    S.tail_v = mgx_plan_v_dev(S.tail);  // the tail's ping-pong buffers may have traded places
+    for (int l = nd - 1; l >= 0; l--) {
+        SLevel &L = S.lv[l];
+        SLevel *C;
+        CoarseShape cs;
+        coarse_of(S, l, C, cs);
+        // initial guess: the interpolated solution of the level below (boundary values stay)
+        OpSpec o;
+        o.pro_stage = 0;
+        o.zero_in = 1;
+        o.store = 1;
+        o.omega = a.omega;
+        o.v_out = L.v[L.cur];
+        o.cs = cs;
+        o.coarse_v = C ? C->v[C->cur] : S.tail_v;
+        col_range(L, 0, -1, o.jlo, o.jhi);
+        S_TRY(fence_pulls(S));
+        S_TRY(launch(S, l, -1, o));
+        // from here on the level below holds coarse-grid corrections: zero, zero boundary
+        if (C) {
+            S_HIP(S, hipMemsetAsync(C->v[0], 0, C->bytes(), S.compute));
+            S_HIP(S, hipMemsetAsync(C->v[1], 0, C->bytes(), S.compute));
+            C->cur = 0;
+        } else {
+            S_HIP(S, hipMemsetAsync(S.tail_v, 0, sizeof(double) * (size_t)mt * mt, S.compute));
+            if (mgx_plan_commit(S.tail) != MGX_OK)
+                return slab_fail(S, MGX_ERR_STATE, "slab %d tail reset: %s", S.rank, mgx_last_error());
+        }
+        CycleArgs sub = a;
+        sub.top = l;
+        S_TRY(slab_cycles(S, sub));
     }
     return MGX_OK;
 }
@@ -785,12 +893,16 @@ int slab_create(Slab &S, const mgx_options *opt)
         S_HIP(S, hipEventCreateWithFlags(&S.done[k], hipEventDisableTiming));
         S_HIP(S, hipEventCreateWithFlags(&S.tready[k], hipEventDisableTiming));
     }
+    // halo widths the arrays must hold: for the whole hierarchy and for every hierarchy that
+    // starts at one of its levels (full multigrid cycles on those too)
     std::vector<int> Evm(nd + 1, 0), Efm(nd + 1, 0);
-    {
+    for (int t = 0; t < nd; t++) {
         std::vector<int> ev, ef;
-        halo_capacity(nd, ev, ef);
-        Evm = ev;
-        Efm = ef;
+        halo_capacity(nd - t, ev, ef);
+        for (int j = 0; j <= nd - t; j++) {
+            Evm[t + j] = std::max(Evm[t + j], ev[j]);
+            Efm[t + j] = std::max(Efm[t + j], ef[j]);
+        }
     }
     S.lv.resize(nd);
     for (int l = 0; l < nd; l++) {
@@ -1091,7 +1203,7 @@ static int mplan_run(mgx_mplan *mp, const CycleArgs &a, double *resnorms, double
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     const int rc = on_every_slab(mp, [&a, mp, t0](Slab &S) {
-        const int rc_ = slab_cycles(S, a);
+        const int rc_ = a.fmg ? slab_fmg(S, a) : slab_cycles(S, a);
         if (rc_ != MGX_OK) return rc_;
         if (S.rank == 0) {
             timespec te;
@@ -1155,6 +1267,19 @@ int mgx_mplan_cycles(mgx_mplan *mp, int Nv, int Ndown, int Nup, double omega, in
     a.Nup = Nup;
     a.omega = omega;
     a.pure_jacobi = pure_jacobi;
+    return mplan_run(mp, a, resnorms, times);
+}
+
+int mgx_mplan_fmg(mgx_mplan *mp, int ncyc, int Ndown, int Nup, double omega, double *resnorms, double *times)
+{
+    if (!mp) return api_fail(MGX_ERR_ARG, "mgx_mplan_fmg: null plan");
+    if (ncyc < 0 || Ndown < 0 || Nup < 0) return api_fail(MGX_ERR_ARG, "mgx_mplan_fmg: negative count");
+    CycleArgs a;
+    a.Nv = ncyc;
+    a.Ndown = Ndown;
+    a.Nup = Nup;
+    a.omega = omega;
+    a.fmg = true;
     return mplan_run(mp, a, resnorms, times);
 }
 

@@ -392,6 +392,13 @@ class MultiPlan:
                                             res.ctypes.data, tim.ctypes.data))
         return MGOutputs(res, tim)
 
+    def fmg(self, ncyc, Ndown, Nup, omega):
+        """EXTENSION: full multigrid over the slabs (mgx_mplan_fmg), same bits as Plan.fmg."""
+        res = np.zeros(ncyc + 1)
+        tim = np.zeros(ncyc + 1)
+        _lib.check(self._L.mgx_mplan_fmg(self._h, ncyc, Ndown, Nup, omega, res.ctypes.data, tim.ctypes.data))
+        return MGOutputs(res, tim)
+
     def profile(self, enable=True):
         _lib.check(self._L.mgx_mplan_profile(self._h, int(bool(enable))))
 

@@ -177,3 +177,52 @@ def test_slabs_of_different_width_agree_on_the_number_of_exchanges(mg, O):
         assert a.ResidualNorms[0] == ref_rn[0]
         assert_bits(b.ResidualNorms, ref_rn, "ResNorms V(%d,%d)" % (nd, nu))
         assert_bits(sol, ref_sol, "Sol V(%d,%d)" % (nd, nu))
+
+
+@pytest.mark.parametrize("R,M,tail_m,ncyc,nd,nu", [(1, 513, 65, 1, 2, 2), (2, 513, 65, 1, 2, 2), (3, 1025, 129, 2, 2, 2),
+                                                  (2, 2049, 257, 1, 2, 2), (4, 2049, 129, 1, 1, 2), (2, 513, 65, 2, 3, 3),
+                                                  (2, 257, 129, 1, 2, 1)])
+def test_full_multigrid_over_slabs_in_one_process(mg, O, R, M, tail_m, ncyc, nd, nu):
+    """mgx_mplan_fmg against the oracle's composition of the reference's operators (mgo_fmg),
+    bit for bit; a second call (staging arrays and counters carried over) gives the same; plain
+    cycles afterwards continue from the result."""
+    f, v0 = _problem(M)
+    dx = 1.0 / (M - 1)
+    ref_sol, ref_rn = O.fmg(f, v0, dx, ncyc, nd, nu, 0.6, 2)
+    P = mg.MultiPlan(M, dx, 2, nslabs=R, devices=[0] * R, tail_m=tail_m)
+    for rep in range(2):
+        P.upload(f, v0)
+        out = P.fmg(ncyc, nd, nu, 0.6)
+        assert_bits(out.ResidualNorms, ref_rn, "FMG ResNorms R=%d call %d" % (R, rep))
+        assert_bits(P.download(), ref_sol, "FMG Sol R=%d call %d" % (R, rep))
+    more = P.cycles(2, nd, nu, 0.6)
+    cont_sol, cont_rn, _ = O.multigrid(f, ref_sol, dx, 2, nd, nu, 0.6, 2)
+    assert_bits(more.ResidualNorms, cont_rn, "cycles after FMG")
+    assert_bits(P.download(), cont_sol, "Sol after FMG + cycles")
+    P.close()
+
+
+def test_full_multigrid_16385_over_four_slabs_equals_the_single_plan(mg):
+    """Full multigrid + V-cycles at 16385^2 over four slabs (tail from 1025^2): history and
+    every column equal mgx_plan_fmg on one device."""
+    import torch
+    from multigrid_amd import rhs
+    from multigrid_amd.solver import _DevPtr
+    M = 16385
+    dx = 1.0 / (M - 1)
+    plan = mg.Plan(M, dx, 2)
+    plan.set(rhs.random_torch(M), mg.colmajor(M, M))
+    ref = plan.fmg(2, 2, 2, 0.6)
+    want = plan.get()
+    P = mg.MultiPlan(M, dx, 2, nslabs=4, devices=[0] * 4)
+    P.set_random_rhs()
+    out = P.fmg(2, 2, 2, 0.6)
+    assert_bits(out.ResidualNorms, ref.ResidualNorms, "FMG ResNorms 16385")
+    for k in range(4):
+        s = P.slab(k)
+        v = torch.as_tensor(_DevPtr(s.v_dev, (s.ncols, s.m)), device="cuda")
+        a = s.own_first - s.col_first
+        assert torch.equal(v[a:a + s.own_count].view(torch.int64),
+                           want.t()[s.own_first:s.own_first + s.own_count].view(torch.int64))
+    P.close()
+    plan.close()

@@ -79,8 +79,12 @@ while time.time() < t_end:
     if mode in (3, 4) and M >= 65:  # the partitioned plan in one process: random slab count, split calls
         R = int(rng.integers(1, 9))
         tail_m = int(rng.choice([17, 33, 65, 129]))
+        use_fmg = bool(rng.integers(0, 3) == 0) and not pj
         try:
-            sol, rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, coarsest, pure_jacobi=pj)
+            if use_fmg:
+                sol, rn = O.fmg(f, v0, dx, Nv, nd, nu, omega, coarsest)
+            else:
+                sol, rn, _ = O.multigrid(f, v0, dx, Nv, nd, nu, omega, coarsest, pure_jacobi=pj)
         except ValueError:
             continue
         try:
@@ -88,6 +92,20 @@ while time.time() < t_end:
         except mg.MgxError:
             continue  # too few columns per slab
         P.upload(f, v0)
+        if use_fmg:
+            if rng.integers(0, 2):
+                P.cycles(1, nd, nu, omega)   # counters and staging parities not at their initial values
+                P.upload(f, v0)
+            out = P.fmg(Nv, nd, nu, omega)
+            v = P.download()
+            P.close()
+            n += 1
+            if not (np.array_equal(out.ResidualNorms.view(np.uint64), rn.view(np.uint64)) and
+                    np.array_equal(v.view(np.uint64), sol.view(np.uint64))):
+                print("MPLAN FMG MISMATCH", dict(M=M, coarsest=coarsest, nd=nd, nu=nu, omega=omega, Nv=Nv, dx=dx,
+                                                 tail_m=tail_m, R=R))
+                sys.exit(1)
+            continue
         k1 = int(rng.integers(0, Nv + 1))
         if os.environ.get("FUZZ_LOG"):
             with open(os.environ["FUZZ_LOG"], "a") as fh:
