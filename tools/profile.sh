@@ -14,6 +14,7 @@ F=$(find $OUT/trace -name '*kernel_trace.csv' | head -1)
 python3 profiles/summarize.py $F > $OUT/fine_level.txt
 python3 profiles/per_launch.py $F > $OUT/per_launch.txt
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
+cp $F $OUT/kernel_trace.csv
 rm -rf $OUT/trace
 MGX_TUNE=0 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > /dev/null 2> $OUT/pmc_fetch.err
 MGX_TUNE=0 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > /dev/null 2> $OUT/pmc_write.err
