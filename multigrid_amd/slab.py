@@ -774,8 +774,9 @@ class SlabSolver:
             self._launch_level0("k_stream:up", make_op, lambda: [self._xv(L0, self.W0)], flip=True)
 
     def cycles(self, Nv, Ndown, Nup, omega, pureJacobi=False):
-        """Nv cycles (main.cpp:309-354).  Returns MGOutputs; Times is the cumulative wall
-        time of the cycles on this rank (a host clock: exchanges are part of a cycle)."""
+        """Nv cycles (main.cpp:309-354).  Returns MGOutputs; Times is the cumulative device time
+        of whole cycles on this rank's stream (events, like the single-device fused schedule;
+        exchanges are part of a cycle); with the CPU test backend it is host time."""
         be = self.be
         slots = be.slots(Nv + 1)
         L0 = self.levels[0]
@@ -790,6 +791,11 @@ class SlabSolver:
         self.comm.exchange([self._xv(L0, self.W0)])
         self._chain(0, "k_stream:norm", L0, 0, 0, 2, 0, omega, norm_slot=be.slot_ptr(slots, 0))
         times = np.zeros(Nv + 1)
+        on_gpu = be.name == "hip"
+        marks = []
+        if on_gpu:
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(Nv + 1)]
+            marks[0].record()
         for it in range(Nv):
             t0 = time.perf_counter()
             slot = be.slot_ptr(slots, it + 1)
@@ -805,9 +811,14 @@ class SlabSolver:
                 self._lean_up0(Ndown, Nup, omega, vt, slot, next_down=it + 1 < Nv)
             else:
                 self._cycle_general(Ndown, Nup, omega, slot, first=it == 0)
-            times[it + 1] = times[it] + (time.perf_counter() - t0)
+            if on_gpu:
+                marks[it + 1].record()
+            else:
+                times[it + 1] = times[it] + (time.perf_counter() - t0)
         self.comm.allreduce_max_(slots)
         be.synchronize()
+        for it in range(Nv if on_gpu else 0):
+            times[it + 1] = times[it] + 1e-3 * marks[it].elapsed_time(marks[it + 1])
         return MGOutputs(be.decode_slots(slots), times)
 
     # ---- full multigrid (an extension; the reference has no such driver) ------------------

@@ -50,5 +50,5 @@ for R in (1, 2, 4, 8):
 S = slab.SlabSolver(M, dx, 2, tail_m=max(257, (M - 1) // 8 + 1))
 S.set_random_rhs()
 w, d = timed(lambda n: S.cycles(n, 2, 2, 0.6))
-print("M=%d  Python slab driver, 1 rank : wall %.3f ms/cycle (its Times are host time: %.3f)" % (M, w, d), flush=True)
+print("M=%d  Python slab driver, 1 rank : wall %.3f ms/cycle, device %.3f ms/cycle" % (M, w, d), flush=True)
 S.close()
