@@ -14,7 +14,7 @@ import subprocess
 from conftest import ROOT
 
 CSRC = os.path.join(ROOT, "multigrid_amd", "csrc")
-SOURCES = ["mgx_kernels.hip", "mgx_stream.hip", "mgx_tail.hip", "mgx_coarse.hip"]
+SOURCES = ["mgx_kernels.hip", "mgx_stream.hip", "mgx_tail.hip", "mgx_coarse.hip", "mgx_noalloc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only"]
 
 
@@ -57,7 +57,7 @@ def test_no_fma_outside_divisions_and_no_scalar_cache_writes(tmp_path):
                 nmul += 1
             assert not scalar_write.search(t), "%s: %s" % (src, t)
         assert not stray, "%s: fused multiply-add outside a division: %s" % (src, stray[:3])
-        assert nmul >= 20, "%s: no fp64 arithmetic found - wrong file?" % src
+        assert nmul >= (5 if src == "mgx_noalloc.hip" else 20), "%s: no fp64 arithmetic found - wrong file?" % src
     # the bit-exact kernels do not divide at all
     for src in ("mgx_kernels.hip", "mgx_stream.hip"):
         assert not any("v_div_scale_f64" in ln for ln in isa[src]), src
