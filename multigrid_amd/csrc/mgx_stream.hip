@@ -645,19 +645,25 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
     if (tune_now_flag()) {
         // Decide at once: a launch reads uin/f/cin and writes uout/cout (never its own input)
         // and merges the norm by a max, so repeating it leaves the same result.  Every
-        // candidate runs once untimed and WINDOW times between one event pair.
+        // candidate runs once untimed and WINDOW times between one event pair, twice.
         hipError_t rc = hipSuccess;
         bool ok = true;
-        for (int k = 0; k < e.ncand && ok; k++) {
-            rc = launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[k], ncolsout, s);
-            ok = rc == hipSuccess && hipEventRecord(e.e0[0], s) == hipSuccess;
-            for (int w = 0; ok && w < ShapeTuner::WINDOW; w++) {
+        // two interleaved passes over the candidates, the smaller time of each counts: a
+        // disturbance during one window (another tenant of the node, a clock ramp) must not
+        // decide between shapes that differ by 2 %
+        for (int pass = 0; pass < 2 && ok; pass++)
+            for (int k = 0; k < e.ncand && ok; k++) {
                 rc = launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[k], ncolsout, s);
-                ok = rc == hipSuccess;
+                ok = rc == hipSuccess && hipEventRecord(e.e0[0], s) == hipSuccess;
+                for (int w = 0; ok && w < ShapeTuner::WINDOW; w++) {
+                    rc = launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[k], ncolsout, s);
+                    ok = rc == hipSuccess;
+                }
+                float t = 0.f;
+                ok = ok && hipEventRecord(e.e1[0], s) == hipSuccess && hipEventSynchronize(e.e1[0]) == hipSuccess &&
+                     hipEventElapsedTime(&t, e.e0[0], e.e1[0]) == hipSuccess;
+                if (ok && (pass == 0 || t < e.time[k])) e.time[k] = t;
             }
-            ok = ok && hipEventRecord(e.e1[0], s) == hipSuccess && hipEventSynchronize(e.e1[0]) == hipSuccess &&
-                 hipEventElapsedTime(&e.time[k], e.e0[0], e.e1[0]) == hipSuccess;
-        }
         if (!ok) {
             if (rc == hipSuccess) (void)hipGetLastError();
             e.chosen = 0;
