@@ -128,6 +128,26 @@ def cpu_baseline(M, nd, nu, omega, omp=False, coarsest=2, exact=False):
                       % (ncyc, nd, nu, M, M, dt)}
 
 
+def cpu_baseline_reference(M, nd, nu, omega, coarsest=2):
+    """The reference's OWN MultiGrid() (main.cpp:283-357 compiled from the reference checkout
+    into oracle/_ref/librefops.so where that checkout exists; the built library travels with
+    the tree) timed on one core: one V-cycle at M x M.  None if the library was not built."""
+    import numpy as np
+    from oracle import oracle as O
+    from multigrid_amd import rhs
+    if O.ref_ops() is None:
+        return None
+    R = O.Ref()
+    f = rhs.random_np(M)
+    v = np.zeros((M, M), order="F")
+    t0 = time.perf_counter()
+    _, _, tim = R.multigrid(f, v, 1.0 / (M - 1), 1, nd, nu, omega, coarsest)
+    dt = time.perf_counter() - t0
+    return {"value": M * M / dt, "unit": "DOF/s", "cores": 1, "kind": "reference",
+            "sample": "1 V(%d,%d) cycle at %dx%d by the reference's MultiGrid() itself (-O2, its Release build uses "
+                      "-Ofast), %.1f s of which %.1f s inside relax() by its own Times" % (nd, nu, M, M, dt, float(tim[-1]))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +317,11 @@ def main():
                                                     args.coarsest, args.exact_coarse)
                 line["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega, True,
                                                               args.coarsest, args.exact_coarse)
+                if not args.exact_coarse:
+                    ref = cpu_baseline_reference(min(args.cpu_size or M, 8193), args.nd, args.nu, args.omega,
+                                                 args.coarsest)
+                    if ref:
+                        line["cpu_baseline_reference"] = ref
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "DOF/s", "cores": 1, "kind": "port",
                                         "sample": "failed: %r" % (e,)}
