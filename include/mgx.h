@@ -169,6 +169,22 @@ int mgx_plan_download(mgx_plan *plan, double *v_host);
 int mgx_plan_cycles(mgx_plan *plan, int Nv, int Ndown, int Nup, double omega, int pure_jacobi,
                     double *resnorms, double *times);
 
+/* EXTENSION for harnesses that want "V-cycles to a tolerance": the reference's stopping rule
+ * is a fixed number of cycles (main.cpp:309), so this is a loop AROUND mgx_plan_cycles(), not
+ * a change of it.  Cycles run in batches of `batch`; after each batch the history is read and
+ * the loop ends when some cycle's norm is at most rel_tol times the initial one
+ * (MGX_STOP_TOLERANCE), when a cycle after the third no longer halves the norm
+ * (MGX_STOP_FLOOR: in fp64 the residual f - Lap_h(u) cannot fall below about
+ * eps * 8/h^2 * max|u|, which at 22529^2 is 4e-8 of a unit right-hand side), or after
+ * max_cycles (MGX_STOP_MAX_CYCLES).  The cycles of the last batch are all run: *cycles_done is a
+ * multiple of `batch` (or max_cycles).  resnorms / times: max_cycles+1 entries, filled up to
+ * *cycles_done; the same bits as one mgx_plan_cycles() call of *cycles_done cycles. */
+#define MGX_STOP_MAX_CYCLES 0
+#define MGX_STOP_TOLERANCE 1
+#define MGX_STOP_FLOOR 2
+int mgx_plan_cycles_until(mgx_plan *plan, int max_cycles, int Ndown, int Nup, double omega, double rel_tol, int batch,
+                          double *resnorms, double *times, int *cycles_done, int *reason);
+
 /* The stream the plan's work is enqueued on from now on (options.stream at creation).  Work
  * already enqueued on the previous stream is ordered before anything that follows. */
 int mgx_plan_set_stream(mgx_plan *plan, void *stream);

@@ -96,6 +96,9 @@ SIGNATURES = {
     "mgx_plan_download": (ctypes.c_int, [_vp, _vp]),
     "mgx_plan_cycles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_int, _vp, _vp]),
+    "mgx_plan_cycles_until": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                             ctypes.c_double, ctypes.c_int, _vp, _vp, ctypes.POINTER(ctypes.c_int),
+                                             ctypes.POINTER(ctypes.c_int)]),
     "mgx_plan_fmg": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, _vp, _vp]),
     "mgx_relax": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double, _vp]),
     "mgx_residual": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, _vp]),
@@ -170,6 +173,7 @@ def check(rc):
 
 
 FLAG_ZERO_GUESS = 1
+STOP_MAX_CYCLES, STOP_TOLERANCE, STOP_FLOOR = 0, 1, 2
 
 
 def make_options(device=-1, stream=None, schedule=SCHEDULE_DEFAULT, verbose=0, coarse_solve=0, ngpus=0, tail_m=0,

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <utility>
 #include <vector>
@@ -886,6 +887,50 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
             times[k] = times[k - 1] + 1e-3 * (double)ms;  // fused: smoothing is not separable, whole-cycle device time
         }
     }
+    return MGX_OK;
+}
+
+int mgx_plan_cycles_until(mgx_plan *p, int max_cycles, int Ndown, int Nup, double omega, double rel_tol, int batch,
+                          double *resnorms, double *times, int *cycles_done, int *reason)
+{
+    if (!p) return fail(MGX_ERR_ARG, "mgx_plan_cycles_until: null plan");
+    if (max_cycles < 0 || Ndown < 0 || Nup < 0 || batch < 1 || !(rel_tol >= 0.0))
+        return fail(MGX_ERR_ARG, "mgx_plan_cycles_until: bad argument");
+    std::vector<double> rn((size_t)batch + 1), tm((size_t)batch + 1);
+    int done = 0, why = MGX_STOP_MAX_CYCLES;
+    double r0 = 0, prev = 0, tbase = 0;
+    if (times) times[0] = 0;
+    while (true) {
+        const int n = std::min(batch, max_cycles - done);
+        // (n == 0 only when max_cycles == 0: the call still yields the initial norm)
+        const int rc = mgx_plan_cycles(p, n, Ndown, Nup, omega, 0, rn.data(), tm.data());
+        if (rc) return rc;
+        if (done == 0) {
+            r0 = rn[0];
+            prev = r0;
+            if (resnorms) resnorms[0] = r0;
+        }
+        bool stop = false;
+        for (int k = 1; k <= n; k++) {
+            if (resnorms) resnorms[done + k] = rn[k];
+            if (times) times[done + k] = tbase + tm[k];
+            // the first cycle at or below the tolerance, or (after the third cycle) the first that no
+            // longer halves the norm: the residual has reached its rounding floor, eps*8/h^2*max|u|
+            if (!stop && rn[k] <= rel_tol * r0) {
+                stop = true;
+                why = MGX_STOP_TOLERANCE;
+            } else if (!stop && done + k > 3 && rn[k] > 0.5 * prev) {
+                stop = true;
+                why = MGX_STOP_FLOOR;
+            }
+            prev = rn[k];
+        }
+        tbase += tm[n];
+        done += n;
+        if (stop || done >= max_cycles) break;
+    }
+    if (cycles_done) *cycles_done = done;
+    if (reason) *reason = why;
     return MGX_OK;
 }
 

@@ -295,6 +295,18 @@ class Plan:
                                            res.ctypes.data, tim.ctypes.data))
         return MGOutputs(res, tim)
 
+    def cycles_until(self, max_cycles, Ndown, Nup, omega, rel_tol, batch=4):
+        """EXTENSION: cycles in batches of `batch` until ||r|| <= rel_tol ||r0||, until the norm
+        stops halving (the fp64 floor of the residual) or until max_cycles (mgx_plan_cycles_until).
+        Returns (MGOutputs of the cycles done, reason) with reason one of _lib.STOP_*."""
+        res = np.zeros(max_cycles + 1)
+        tim = np.zeros(max_cycles + 1)
+        done, why = ctypes.c_int(0), ctypes.c_int(0)
+        self._on_current_stream()
+        _lib.check(self._L.mgx_plan_cycles_until(self._h, max_cycles, Ndown, Nup, omega, rel_tol, batch, res.ctypes.data,
+                                                 tim.ctypes.data, ctypes.byref(done), ctypes.byref(why)))
+        return MGOutputs(res[:done.value + 1], tim[:done.value + 1]), why.value
+
     def fmg(self, ncyc, Ndown, Nup, omega):
         """EXTENSION (not in the reference): full multigrid -- the right-hand side restricted to
         every level, the coarsest grid solved, then ncyc V(Ndown,Nup) cycles per level on the way

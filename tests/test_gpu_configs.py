@@ -279,3 +279,35 @@ def test_65537_both_schedules_agree(mg):
     assert_bits(res[0][0], res[1][0], "ResNorms 65537")
     assert res[0][1] == res[1][1]
     assert res[0][0][3] < 0.5 * res[0][0][1]
+
+
+def test_cycles_to_a_tolerance_257(mg, O, known, f_smooth_257):
+    """257^2, V(2,2) "to 1e-8" (the CPU-runnable configuration): the reference reaches 1e-8 in
+    absolute terms at cycle 17 (its known answer); relative to the initial norm 5.35 the
+    tolerance is 5.35e-8, reached at cycle 15 (the rounding floor, 9e-12, follows at cycle 23).  The tolerance loop runs whole batches and returns the same
+    bits as the oracle's history up to where it stopped; at a tolerance below the fp64 floor it
+    stops for that reason instead of running on."""
+    from multigrid_amd import _lib
+    M = 257
+    dx = 1.0 / (M - 1)
+    sol, rn, _ = O.multigrid(f_smooth_257, np.zeros((M, M), order="F"), dx, 40, 2, 2, 0.6, 2)
+    first = int(np.argmax(rn <= 1e-8 * rn[0]))
+    assert int(np.argmax(rn <= 1e-8)) == known["case257"]["first_cycle_le_1e-8"]
+    for batch in (1, 4, 7):
+        plan = mg.Plan(M, dx, 2)
+        plan.set(mg.to_device(f_smooth_257), mg.colmajor(M, M))
+        out, why = plan.cycles_until(40, 2, 2, 0.6, 1e-8, batch=batch)
+        done = len(out.ResidualNorms) - 1
+        assert why == _lib.STOP_TOLERANCE
+        assert done == -(-first // batch) * batch            # the batch that contains the first cycle below
+        assert_bits(out.ResidualNorms, rn[:done + 1], "ResNorms to 1e-8, batch %d" % batch)
+        ref_sol, _, _ = O.multigrid(f_smooth_257, np.zeros((M, M), order="F"), dx, done, 2, 2, 0.6, 2)
+        assert_bits(mg.to_numpy(plan.get()), ref_sol, "Sol to 1e-8, batch %d" % batch)
+        plan.close()
+    plan = mg.Plan(M, dx, 2)
+    plan.set(mg.to_device(f_smooth_257), mg.colmajor(M, M))
+    out, why = plan.cycles_until(60, 2, 2, 0.6, 1e-15, batch=2)
+    assert why == _lib.STOP_FLOOR and len(out.ResidualNorms) - 1 < 40
+    out, why = plan.cycles_until(0, 2, 2, 0.6, 1e-8)
+    assert why == _lib.STOP_MAX_CYCLES and out.ResidualNorms.shape == (1,)
+    plan.close()
