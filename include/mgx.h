@@ -375,6 +375,16 @@ typedef struct mgx_mplan mgx_mplan;
 int mgx_mplan_create(mgx_mplan **plan, int m, double dx, int coarsest, int nslabs, const int *devices,
                      const mgx_options *opt);
 int mgx_mplan_destroy(mgx_mplan *plan);
+/* The decomposition mgx_mplan_create() would choose, computed on the host (no GPU needed):
+ * *distributed_levels = nd, and bounds[l*(nslabs+1) + g] = first global column slab g owns of
+ * level l, for l = 0..nd (level nd is the top of the tail) and g = 0..nslabs (entry nslabs is
+ * the size of the level).  bounds may be NULL; otherwise bounds_len >= (nd+1)*(nslabs+1).
+ * tail_m = 0 takes the default.  mgx_halo_plan: the halo widths of the lean schedule
+ * (Ndown+Nup in 1..4) for nd distributed levels, Ev[0..nd] / Ef[0..nd]: columns beyond its
+ * own that a slab computes of the level-l iterate / holds of the level-l right-hand side. */
+int mgx_mplan_partition(int m, int coarsest, int nslabs, int tail_m, int *distributed_levels, int *bounds,
+                        int bounds_len);
+int mgx_halo_plan(int distributed_levels, int Ndown, int Nup, int *Ev, int *Ef);
 int mgx_mplan_nslabs(const mgx_mplan *plan);
 int mgx_mplan_depth(const mgx_mplan *plan);
 int mgx_mplan_distributed_levels(const mgx_mplan *plan); /* levels split over the slabs          */

@@ -119,6 +119,10 @@ SIGNATURES = {
     "mgx_mplan_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int,
                                         _vp, _vp]),
     "mgx_mplan_destroy": (ctypes.c_int, [_vp]),
+    "mgx_mplan_partition": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "mgx_halo_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                     ctypes.POINTER(ctypes.c_int)]),
     "mgx_mplan_nslabs": (ctypes.c_int, [_vp]),
     "mgx_mplan_depth": (ctypes.c_int, [_vp]),
     "mgx_mplan_distributed_levels": (ctypes.c_int, [_vp]),

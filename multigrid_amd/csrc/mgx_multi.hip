@@ -949,6 +949,75 @@ int slab_create(Slab &S, const mgx_options *opt)
     return MGX_OK;
 }
 
+// Which levels are split and who owns what: levels 0..nd-1 are distributed, level nd is the
+// top of the tail (a plan of its own, whose finest level must be odd: an even coarsest level
+// cannot be the whole tail).  tail_m <= 0 picks the default: every slab repeats the tail, so
+// its cost does not shrink with the number of slabs while a distributed level's does -- the
+// more slabs, the smaller the tail (2049 on one slab, 1025 on several).  bounds[l][g] is the
+// first global column slab g owns of level l (bounds[l][R] = size of the level).
+int partition(const std::vector<int> &dims, int R, int tail_m, int &tail_m_used, int &nd_out,
+              std::vector<std::vector<int>> &bounds)
+{
+    const int depth = (int)dims.size() - 1;
+    if (tail_m <= 0) tail_m = R == 1 ? 2049 : 1025;
+    tail_m_used = tail_m;
+    const int max_nd = depth - ((dims.back() % 2) == 0 ? 1 : 0);
+    int nd = 0;
+    while (nd < max_nd && dims[nd] > tail_m) {
+        // would every slab still own a halo's worth of columns of every level, for every
+        // sub-hierarchy, if one more level were distributed?
+        std::vector<int> Ev(nd + 2, 0), Ef(nd + 2, 0);
+        for (int s = 0; s <= nd; s++) {
+            std::vector<int> ev, ef;
+            halo_capacity(nd + 1 - s, ev, ef);
+            for (int j = 0; j <= nd + 1 - s; j++) {
+                Ev[s + j] = std::max(Ev[s + j], ev[j]);
+                Ef[s + j] = std::max(Ef[s + j], ef[j]);
+            }
+        }
+        const int base = (dims[nd + 1] - 2) / R;
+        bool fits = base >= 1;
+        for (int l = 0; l <= nd; l++) {
+            const long own = (long)base * (1L << (nd + 1 - l)) - 1;
+            const int need = l == 0 ? W0 : std::max(W0, std::max(Ef[l], Ev[l]));
+            fits = fits && own >= need;
+        }
+        if (R > 1 && !fits) break;
+        nd++;
+    }
+    if (nd == 0)
+        return api_fail(MGX_ERR_ARG, "a %dx%d grid is not split over %d slab(s) with tail_m=%d: solve it with "
+                                     "mgx_plan_* on one device", dims[0], dims[0], R, tail_m);
+    nd_out = nd;
+    const int mt = dims[nd];
+    bounds.assign(nd + 1, std::vector<int>(R + 1, 0));
+    for (int g = 1; g < R; g++) bounds[nd][g] = 1 + (int)(((long)g * (mt - 2)) / R);
+    bounds[nd][R] = mt;
+    for (int l = nd - 1; l >= 0; l--) {
+        for (int g = 1; g < R; g++) bounds[l][g] = 2 * bounds[l + 1][g] - 1;
+        bounds[l][R] = dims[l];
+    }
+    return MGX_OK;
+}
+
+// the sizes of the levels (main.cpp:286,293) or an error code
+int level_sizes(int m, int coarsest, std::vector<int> &dims)
+{
+    if (m < 3) return api_fail(MGX_ERR_ARG, "grid size %d is below 3", m);
+    if ((m % 2) == 0) return api_fail(MGX_ERR_ARG, "Input has even rows and columns! (m=%d)", m);
+    if (coarsest < 1) return api_fail(MGX_ERR_ARG, "coarsest must be >= 1 (got %d)", coarsest);
+    const int depth = mgx_depth(m, coarsest);
+    if (depth < 0) return api_fail(MGX_ERR_HIERARCHY, "depth %d < 0 for m=%d coarsest=%d", depth, m, coarsest);
+    dims.assign(1, m);
+    for (int d = 1; d <= depth; d++) {
+        dims.push_back((dims.back() - 1) / 2 + 1);  // main.cpp:293
+        if (dims[d] < 3 || ((dims[d] % 2) == 0 && d < depth))
+            return api_fail(MGX_ERR_HIERARCHY, "level %d would be %dx%d (needs odd >= 3): the reference indexes out "
+                                               "of range there", d, dims[d], dims[d]);
+    }
+    return MGX_OK;
+}
+
 template <class F>
 int on_every_slab(mgx_mplan *mp, F fn)
 {
@@ -983,6 +1052,39 @@ int on_every_slab(mgx_mplan *mp, F fn)
 } // namespace
 
 extern "C" {
+
+int mgx_mplan_partition(int m, int coarsest, int nslabs, int tail_m, int *distributed_levels, int *bounds, int bounds_len)
+{
+    if (nslabs < 1 || nslabs > 64) return api_fail(MGX_ERR_ARG, "mgx_mplan_partition: nslabs %d outside 1..64", nslabs);
+    std::vector<int> dims;
+    int rc = level_sizes(m, coarsest, dims);
+    if (rc != MGX_OK) return rc;
+    int used = 0, nd = 0;
+    std::vector<std::vector<int>> b;
+    rc = partition(dims, nslabs, tail_m, used, nd, b);
+    if (rc != MGX_OK) return rc;
+    if (distributed_levels) *distributed_levels = nd;
+    if (bounds) {
+        if (bounds_len < (nd + 1) * (nslabs + 1))
+            return api_fail(MGX_ERR_ARG, "mgx_mplan_partition: bounds needs %d entries", (nd + 1) * (nslabs + 1));
+        for (int l = 0; l <= nd; l++)
+            for (int g = 0; g <= nslabs; g++) bounds[l * (nslabs + 1) + g] = b[l][g];
+    }
+    return MGX_OK;
+}
+
+int mgx_halo_plan(int distributed_levels, int Ndown, int Nup, int *Ev, int *Ef)
+{
+    if (distributed_levels < 1 || Ndown < 0 || Nup < 0 || Ndown + Nup < 1 || Ndown + Nup > MAX_LEAN || !Ev || !Ef)
+        return api_fail(MGX_ERR_ARG, "mgx_halo_plan: bad argument");
+    std::vector<int> ev, ef;
+    halo_plan(distributed_levels, Ndown, Nup, ev, ef);
+    for (int l = 0; l <= distributed_levels; l++) {
+        Ev[l] = ev[l];
+        Ef[l] = ef[l];
+    }
+    return MGX_OK;
+}
 
 int mgx_mplan_create(mgx_mplan **out, int m, double dx, int coarsest, int nslabs, const int *devices,
                      const mgx_options *opt)
@@ -1026,52 +1128,13 @@ int mgx_mplan_create(mgx_mplan **out, int m, double dx, int coarsest, int nslabs
         const char *e = getenv("MGX_TAIL_M");
         tail_m = e ? atoi(e) : 0;
     }
-    // every slab repeats the tail, so its cost does not shrink with the number of slabs while
-    // a distributed level's does: the more slabs, the smaller the tail
-    if (tail_m <= 0) tail_m = R == 1 ? 2049 : 1025;
-    mp->tail_m = tail_m;
     {
         const char *e = getenv("MGX_SLAB_OVERLAP");
         mp->overlap = (e && atoi(e) == 0) ? 0 : 1;
     }
-    // levels 0..nd-1 are distributed, level nd is the top of the tail (a plan of its own,
-    // whose finest level must be odd: an even coarsest level cannot be the whole tail)
-    const std::vector<int> &dims = mp->dims;
-    const int max_nd = depth - ((dims.back() % 2) == 0 ? 1 : 0);
-    int nd = 0;
-    while (nd < max_nd && dims[nd] > tail_m) {
-        // would every slab still own a halo's worth of columns of every level, for every
-        // sub-hierarchy, if one more level were distributed?
-        std::vector<int> Ev(nd + 2, 0), Ef(nd + 2, 0);
-        for (int s = 0; s <= nd; s++) {
-            std::vector<int> ev, ef;
-            halo_capacity(nd + 1 - s, ev, ef);
-            for (int j = 0; j <= nd + 1 - s; j++) {
-                Ev[s + j] = std::max(Ev[s + j], ev[j]);
-                Ef[s + j] = std::max(Ef[s + j], ef[j]);
-            }
-        }
-        const int base = (dims[nd + 1] - 2) / R;
-        bool fits = base >= 1;
-        for (int l = 0; l <= nd; l++) {
-            const long own = (long)base * (1L << (nd + 1 - l)) - 1;
-            const int need = l == 0 ? W0 : std::max(W0, std::max(Ef[l], Ev[l]));
-            fits = fits && own >= need;
-        }
-        if (R > 1 && !fits) break;
-        nd++;
-    }
-    if (nd == 0)
-        return api_fail(MGX_ERR_ARG, "mgx_mplan_create: a %dx%d grid is not split over %d slab(s) with tail_m=%d: "
-                                     "solve it with mgx_plan_* on one device", m, m, R, tail_m);
-    mp->nd = nd;
-    const int mt = dims[nd];
-    mp->bounds.assign(nd + 1, std::vector<int>(R + 1, 0));
-    for (int g = 1; g < R; g++) mp->bounds[nd][g] = 1 + (int)(((long)g * (mt - 2)) / R);
-    mp->bounds[nd][R] = mt;
-    for (int l = nd - 1; l >= 0; l--) {
-        for (int g = 1; g < R; g++) mp->bounds[l][g] = 2 * mp->bounds[l + 1][g] - 1;
-        mp->bounds[l][R] = dims[l];
+    {
+        const int rc = partition(mp->dims, R, tail_m, mp->tail_m, mp->nd, mp->bounds);
+        if (rc != MGX_OK) return rc;
     }
     mp->posted.reset(new std::atomic<long>[R]);
     mp->pulled.reset(new std::atomic<long>[R]);
