@@ -72,7 +72,10 @@ struct Geo {
     static constexpr int HL = NS + (RES ? 2 : (NM == NS ? 1 : 0));
     static constexpr int HH = NS + (RESID_END ? 1 : 0) + (PA == 0 ? 1 : 0);
     static constexpr int PADLO = (HL + 1) & ~1;            // even, so that r0 is even
-    static constexpr int S = (128 - PADLO - HH) & ~1;      // rows owned per strip (even)
+#ifndef MGX_STRIP_SHRINK
+#define MGX_STRIP_SHRINK 0  // experiment knob: rows a strip gives up (a larger share of halo rows)
+#endif
+    static constexpr int S = ((128 - PADLO - HH) & ~1) - MGX_STRIP_SHRINK;  // rows owned per strip (even)
     // columns of halo a chunk consumes before its first owned column
     static constexpr int HLC = HL;
     // last input column the march must reach, relative to the chunk end jb
