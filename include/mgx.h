@@ -47,7 +47,8 @@ typedef struct mgx_options {
     int coarse_solve; /* MGX_COARSE_REFERENCE (0, default) or MGX_COARSE_EXACT, see below           */
     int ngpus;        /* mgx_solve2d: 0 or 1 = one device (default); N > 1 = the grid is split into
                          N j-slabs, slab k on device k modulo the number of visible devices
-                         (mgx_mplan_*, below).  A grid too small to split runs on one device.   */
+                         (mgx_mplan_*, below).  A grid too small to split, or the stepwise
+                         schedule (which exists on one device only), runs on one device.        */
     int tail_m;       /* partitioned runs: largest level (points per side) that every slab
                          holds whole instead of a share of; 0 = default (1025, MGX_TAIL_M)      */
     int flags;        /* MGX_FLAG_* bits, see below                                             */
