@@ -88,6 +88,9 @@ struct mgx_plan {
     int coarse_solve = MGX_COARSE_REFERENCE;
     double *exact_tables = nullptr;      // device tables of the exact coarsest-grid solve, or null
     int use_tail = 1;  // levels <= 65x65 of a cycle in one LDS-resident launch (MGX_NO_TAIL=1 disables)
+    // groups of levels of at most mid_max_m rows in one launch per direction (mgx_mid.hip;
+    // MGX_NO_MID=1 disables, MGX_MID_MAX_M / MGX_MID_DOWN_NL / MGX_MID_UP_NL size the groups)
+    int use_mid = 1, mid_max_m = 513, mid_nl_down = 2, mid_nl_up = 4;
     std::vector<Level> lv;
     double *r = nullptr;                 // residual scratch of the stepwise schedule (fine size)
     unsigned long long *slots = nullptr; // encoded norms, one per cycle (+1)
@@ -487,15 +490,72 @@ int fused_tail(mgx_plan *p, int T, const FusedCtx &cx)
     return MGX_OK;
 }
 
-// levels 1..depth-1 down, the coarsest solve, levels depth-1..1 up
-int fused_coarse_legs(mgx_plan *p, const FusedCtx &cx)
+// ---- groups of small levels in one launch (mgx_mid.hip) -----------------------
+MidArgs mid_args(const mgx_plan *p, int d, int nl, const FusedCtx &cx)
+{
+    MidArgs A;
+    A.nl = nl;
+    for (int k = 0; k <= nl; k++) A.m[k] = p->lv[d + k].m;
+    for (int k = 0; k < nl; k++) {
+        const SweepCoef c = make_coef(p->lv[d + k].dx, cx.omega);
+        A.h2[k] = c.h2;
+        A.invh2[k] = c.invh2;
+        A.f[k] = p->lv[d + k].f;
+    }
+    for (int k = 1; k <= nl; k++) A.fo[k] = p->lv[d + k].f;
+    A.ndown = cx.Ndown;
+    A.nup = cx.Nup;
+    A.omega = cx.omega;
+    A.nomega = 1 - cx.omega;
+    return A;
+}
+
+// How many of the levels d..last one launch takes, starting at d; 1: level d runs its own
+// streaming leg.  Groups are cut so that a remainder stays at the fine end, where a
+// level is big enough for the streaming kernel.
+int mid_group(const mgx_plan *p, const FusedCtx &cx, int d, int last, bool down)
+{
+    if (!p->use_mid || !cx.lean() || !cx.zero_start(d) || p->lv[d].m > p->mid_max_m) return 1;
+    const int cap = down ? p->mid_nl_down : p->mid_nl_up;
+    const int n = last - d + 1;
+    if (cap < 2 || n < 2) return 1;
+    for (int g = (n % cap == 0) ? cap : n % cap; g >= 2; g--)
+        if (mid_fits(down, mid_args(p, d, g, cx))) return g;
+    return 1;
+}
+
+// down legs of levels d..d+nl-1 (main.cpp:321-327): lv[d].f -> lv[d+1..d+nl].f
+int mid_down(mgx_plan *p, int d, int nl, const FusedCtx &cx)
+{
+    const MidArgs A = mid_args(p, d, nl, cx);
+    LAUNCH(p, d, MGX_KERNEL_FUSED_DOWN, launch_mid_down(A, p->stream));
+    return MGX_OK;
+}
+
+// up legs of levels d+nl-1..d (main.cpp:337-344): iterate of level d+nl -> lv[d].v[0]
+int mid_up(mgx_plan *p, int d, int nl, const FusedCtx &cx)
+{
+    MidArgs A = mid_args(p, d, nl, cx);
+    const Level &C = p->lv[d + nl];
+    A.cv = C.v[C.cur];
+    A.v = p->lv[d].v[0];
+    p->lv[d].cur = 0;
+    LAUNCH(p, d, MGX_KERNEL_FUSED_UP, launch_mid_up(A, p->stream));
+    return MGX_OK;
+}
+
+// levels first..depth-1 down, the coarsest solve, levels depth-1..first up; every one of them
+// starts from a zero iterate (first = 1, or 0 for a plan whose top level does too)
+int fused_coarse_legs(mgx_plan *p, const FusedCtx &cx, int first = 1)
 {
     const int depth = p->depth;
     const int T = tail_first_level(p, cx);
     const int last = (T >= 1) ? T - 1 : depth - 1;  // last level that runs its own legs
-    for (int d = 1; d <= last; d++) {
-        int rc = fused_down(p, d, cx);
+    for (int d = first; d <= last;) {
+        const int g = mid_group(p, cx, d, last, true);
+        const int rc = g >= 2 ? mid_down(p, d, g, cx) : fused_down(p, d, cx);
         if (rc) return rc;
+        d += g;
     }
     if (T >= 1) {
         int rc = fused_tail(p, T, cx);
@@ -504,8 +564,16 @@ int fused_coarse_legs(mgx_plan *p, const FusedCtx &cx)
         int rc = coarsest_solve(p);
         if (rc) return rc;
     }
-    for (int d = last; d >= 1; d--) {
-        int rc = fused_up(p, d, cx, nullptr, false);
+    // the up legs: groups cut from the fine end like the down legs, run from the coarse end
+    std::vector<std::pair<int, int>> groups;
+    for (int d = first; d <= last;) {
+        const int g = mid_group(p, cx, d, last, false);
+        groups.push_back({d, g});
+        d += g;
+    }
+    for (size_t q = groups.size(); q-- > 0;) {
+        const int d = groups[q].first, g = groups[q].second;
+        const int rc = g >= 2 ? mid_up(p, d, g, cx) : fused_up(p, d, cx, nullptr, false);
         if (rc) return rc;
     }
     return MGX_OK;
@@ -517,6 +585,7 @@ int vcycle_fused(mgx_plan *p, int Ndown, int Nup, double omega, unsigned long lo
     FusedCtx cx{Ndown, Nup, omega, zero0};
     if (zero0 && tail_first_level(p, cx) == 0) return fused_tail(p, 0, cx);  // the whole plan fits the tail
     if (p->depth == 0) return coarsest_solve(p);
+    if (zero0 && !norm_slot) return fused_coarse_legs(p, cx, 0);  // level 0 is one of the zero-start levels
     int rc = fused_down(p, 0, cx);
     if (!rc) rc = fused_coarse_legs(p, cx);
     if (!rc && !zero0) rc = normalize_boundary(p);
@@ -618,6 +687,10 @@ static int plan_create_on_device(mgx_plan **out, int m, double dx, int coarsest,
     p->coarsest = coarsest;
     p->depth = depth;
     p->use_tail = getenv("MGX_NO_TAIL") ? 0 : 1;
+    p->use_mid = getenv("MGX_NO_MID") ? 0 : 1;
+    if (const char *e = getenv("MGX_MID_MAX_M")) p->mid_max_m = atoi(e);
+    if (const char *e = getenv("MGX_MID_DOWN_NL")) p->mid_nl_down = std::min(std::max(atoi(e), 1), MID_MAX_LEVELS);
+    if (const char *e = getenv("MGX_MID_UP_NL")) p->mid_nl_up = std::min(std::max(atoi(e), 1), MID_MAX_LEVELS);
     p->lv.resize(depth + 1);
     double h = dx;
     for (int d = 0; d <= depth; d++) {
@@ -1027,6 +1100,10 @@ int mgx_plan_fmg(mgx_plan *p, int ncyc, int Ndown, int Nup, double omega, double
         view.coarse_solve = p->coarse_solve;
         view.exact_tables = p->exact_tables;
         view.use_tail = p->use_tail;
+        view.use_mid = p->use_mid;
+        view.mid_max_m = p->mid_max_m;
+        view.mid_nl_down = p->mid_nl_down;
+        view.mid_nl_up = p->mid_nl_up;
         view.lv.assign(p->lv.begin() + l, p->lv.end());
         view.r = p->r;
         view.slots = p->slots;

@@ -126,6 +126,30 @@ size_t tail_lds_bytes(const TailArgs &A);  // hierarchy + tables
 // One V(Ndown,Nup) cycle over the tail's levels from a zero iterate on its top level.
 hipError_t launch_tail(const TailArgs &A, hipStream_t s);
 
+// ---- groups of small levels in one launch (mgx_mid.hip) ------------------------
+// For levels that start the down sweep from a zero iterate, with the lean bookkeeping (no
+// iterate stored on the way down, pre-smoothing recomputed on the way up).
+static constexpr int MID_MAX_LEVELS = 5;
+struct MidArgs {
+    int nl = 0;                                   // levels in the group; local level 0 is the finest
+    int m[MID_MAX_LEVELS + 1] = {0};              // rows of local levels 0..nl (nl: the level below the group)
+    double h2[MID_MAX_LEVELS] = {0}, invh2[MID_MAX_LEVELS] = {0};
+    const double *f[MID_MAX_LEVELS] = {nullptr};  // right-hand sides of levels 0..nl-1 (down reads f[0] only)
+    double *fo[MID_MAX_LEVELS + 1] = {nullptr};   // down: right-hand sides of levels 1..nl, written
+    const double *cv = nullptr;                   // up: iterate of level nl, read with its boundary
+    double *v = nullptr;                          // up: iterate of level 0, interior written
+    int ndown = 0, nup = 0;
+    double omega = 0, nomega = 0;
+    // filled by the launcher: tile a workgroup owns (rows x columns of the output level),
+    // tiles per axis, doubles per LDS array, position of each level's right-hand side in LDS
+    int tile_i = 0, tile_j = 0, nti = 0, ntj = 0, stride = 0;
+    int foff[MID_MAX_LEVELS] = {0};
+};
+// whether a launch for these levels and sweep counts exists (odd nested sizes, tiles that fit LDS)
+bool mid_fits(bool down, const MidArgs &A);
+hipError_t launch_mid_down(const MidArgs &A, hipStream_t s);
+hipError_t launch_mid_up(const MidArgs &A, hipStream_t s);
+
 // ---- fused streaming kernels (mgx_stream.hip) --------------------------------
 // One launch = [prolong + correct] -> ns Jacobi sweeps -> [residual -> restrict | norm].
 struct StreamArgs {

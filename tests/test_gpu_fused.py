@@ -19,8 +19,6 @@ def _rand(m, seed, scale=1.0):
 @pytest.mark.parametrize("m", SIZES)
 @pytest.mark.parametrize("ns", [0, 1, 2, 3, 4, 5, 9])
 def test_fused_down(mg, O, m, ns):
-    if m > 600 and ns not in (2, 3, 9):
-        pytest.skip("large sizes run a subset of sweep counts")
     u, f = _rand(m, m + ns), _rand(m, m + ns + 1, 30.0)
     dx = 1.0 / (m - 1)
     omega = 0.6 if ns % 2 == 0 else 0.85
@@ -35,8 +33,6 @@ def test_fused_down(mg, O, m, ns):
 @pytest.mark.parametrize("m", SIZES)
 @pytest.mark.parametrize("ns", [0, 1, 2, 3, 4, 6])
 def test_fused_up(mg, O, m, ns):
-    if m > 600 and ns not in (0, 2, 6):
-        pytest.skip("large sizes run a subset of sweep counts")
     mc = (m - 1) // 2 + 1
     u, f, c = _rand(m, 2 * m + ns), _rand(m, 2 * m + ns + 1, 30.0), _rand(mc, 2 * m + ns + 2)
     # the coarse iterate has a zero boundary in the solver (main.cpp:295-299)

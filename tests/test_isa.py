@@ -14,7 +14,7 @@ import subprocess
 from conftest import ROOT
 
 CSRC = os.path.join(ROOT, "multigrid_amd", "csrc")
-SOURCES = ["mgx_kernels.hip", "mgx_stream.hip", "mgx_tail.hip", "mgx_coarse.hip", "mgx_noalloc.hip"]
+SOURCES = ["mgx_kernels.hip", "mgx_stream.hip", "mgx_tail.hip", "mgx_coarse.hip", "mgx_noalloc.hip", "mgx_mid.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only"]
 
 
