@@ -91,6 +91,8 @@ struct mgx_plan {
     // groups of levels of at most mid_max_m rows in one launch per direction (mgx_mid.hip;
     // MGX_NO_MID=1 disables, MGX_MID_MAX_M / MGX_MID_DOWN_NL / MGX_MID_UP_NL size the groups)
     int use_mid = 1, mid_max_m = 513, mid_nl_down = 2, mid_nl_up = 4;
+    int mid_single_down_m = 1025, mid_single_up_m = 1025;  // MGX_MID_SINGLE_DOWN / MGX_MID_SINGLE_UP
+    int tail_small_m = 33;  // a tail level above this size goes to a grouped launch where one exists (MGX_TAIL_SMALL_M)
     std::vector<Level> lv;
     double *r = nullptr;                 // residual scratch of the stepwise schedule (fine size)
     unsigned long long *slots = nullptr; // encoded norms, one per cycle (+1)
@@ -443,12 +445,18 @@ int fused_up(mgx_plan *p, int d, const FusedCtx &cx, unsigned long long *slot, b
     return stream_chain(p, d, MGX_KERNEL_FUSED_UP, p->stream, 1, cx.Nup, slot ? 2 : 0, 0, A, L.v, L.cur);
 }
 
+MidArgs mid_args(const mgx_plan *p, int d, int nl, const FusedCtx &cx);
+
 // First level of the LDS-resident tail: the first zero-start level of at most
 // TAIL_MAX_M points per side (level 0 only when it starts from zero), or -1.
+// One workgroup spends 10 us of the tail's 25 on a 65x65 level, so where the grouped
+// launches (mgx_mid.hip) can take that level along with the one above it, at next to no
+// cost, the tail starts one level further down.
 int tail_first_level(const mgx_plan *p, const FusedCtx &cx)
 {
     if (!p->use_tail) return -1;
-    for (int d = cx.zero0 ? 0 : 1; d <= p->depth; d++) {
+    const int first = cx.zero0 ? 0 : 1;
+    for (int d = first; d <= p->depth; d++) {
         if (p->lv[d].m > TAIL_MAX_M) continue;
         if (p->depth - d + 1 > TAIL_MAX_LEVELS) return -1;
         size_t n = 0;
@@ -457,7 +465,12 @@ int tail_first_level(const mgx_plan *p, const FusedCtx &cx)
             const size_t nc = (size_t)p->lv[p->depth].m - 2;
             n += (nc * nc + nc) * sizeof(double);
         }
-        return n <= TAIL_MAX_LDS_BYTES ? d : -1;
+        if (n > TAIL_MAX_LDS_BYTES) return -1;
+        if (p->use_mid && cx.lean() && d - 1 >= first && d < p->depth && p->lv[d].m > p->tail_small_m &&
+            p->lv[d - 1].m <= p->mid_max_m && p->mid_nl_down >= 2 && p->mid_nl_up >= 2 &&
+            mid_fits(true, mid_args(p, d - 1, 2, cx)) && mid_fits(false, mid_args(p, d - 1, 2, cx)))
+            return d + 1;
+        return d;
     }
     return -1;
 }
@@ -524,6 +537,15 @@ int mid_group(const mgx_plan *p, const FusedCtx &cx, int d, int last, bool down)
     return 1;
 }
 
+// A level that joins no group still gains from the tiled kernel while it is small enough
+// for latency, not bandwidth, to set the time of its streaming leg (measured: 1025^2 down
+// 9.8 -> 7.3 us, up 14.5 -> 11.1 us; at 2049^2 the streaming kernel wins both ways).
+bool mid_single(const mgx_plan *p, const FusedCtx &cx, int d, bool down)
+{
+    const int most = down ? p->mid_single_down_m : p->mid_single_up_m;
+    return p->use_mid && cx.lean() && cx.zero_start(d) && p->lv[d].m <= most && mid_fits(down, mid_args(p, d, 1, cx));
+}
+
 // down legs of levels d..d+nl-1 (main.cpp:321-327): lv[d].f -> lv[d+1..d+nl].f
 int mid_down(mgx_plan *p, int d, int nl, const FusedCtx &cx)
 {
@@ -553,7 +575,7 @@ int fused_coarse_legs(mgx_plan *p, const FusedCtx &cx, int first = 1)
     const int last = (T >= 1) ? T - 1 : depth - 1;  // last level that runs its own legs
     for (int d = first; d <= last;) {
         const int g = mid_group(p, cx, d, last, true);
-        const int rc = g >= 2 ? mid_down(p, d, g, cx) : fused_down(p, d, cx);
+        const int rc = (g >= 2 || mid_single(p, cx, d, true)) ? mid_down(p, d, g, cx) : fused_down(p, d, cx);
         if (rc) return rc;
         d += g;
     }
@@ -573,7 +595,7 @@ int fused_coarse_legs(mgx_plan *p, const FusedCtx &cx, int first = 1)
     }
     for (size_t q = groups.size(); q-- > 0;) {
         const int d = groups[q].first, g = groups[q].second;
-        const int rc = g >= 2 ? mid_up(p, d, g, cx) : fused_up(p, d, cx, nullptr, false);
+        const int rc = (g >= 2 || mid_single(p, cx, d, false)) ? mid_up(p, d, g, cx) : fused_up(p, d, cx, nullptr, false);
         if (rc) return rc;
     }
     return MGX_OK;
@@ -689,6 +711,9 @@ static int plan_create_on_device(mgx_plan **out, int m, double dx, int coarsest,
     p->use_tail = getenv("MGX_NO_TAIL") ? 0 : 1;
     p->use_mid = getenv("MGX_NO_MID") ? 0 : 1;
     if (const char *e = getenv("MGX_MID_MAX_M")) p->mid_max_m = atoi(e);
+    if (const char *e = getenv("MGX_TAIL_SMALL_M")) p->tail_small_m = atoi(e);
+    if (const char *e = getenv("MGX_MID_SINGLE_DOWN")) p->mid_single_down_m = atoi(e);
+    if (const char *e = getenv("MGX_MID_SINGLE_UP")) p->mid_single_up_m = atoi(e);
     if (const char *e = getenv("MGX_MID_DOWN_NL")) p->mid_nl_down = std::min(std::max(atoi(e), 1), MID_MAX_LEVELS);
     if (const char *e = getenv("MGX_MID_UP_NL")) p->mid_nl_up = std::min(std::max(atoi(e), 1), MID_MAX_LEVELS);
     p->lv.resize(depth + 1);
@@ -1102,6 +1127,9 @@ int mgx_plan_fmg(mgx_plan *p, int ncyc, int Ndown, int Nup, double omega, double
         view.use_tail = p->use_tail;
         view.use_mid = p->use_mid;
         view.mid_max_m = p->mid_max_m;
+        view.tail_small_m = p->tail_small_m;
+        view.mid_single_down_m = p->mid_single_down_m;
+        view.mid_single_up_m = p->mid_single_up_m;
         view.mid_nl_down = p->mid_nl_down;
         view.mid_nl_up = p->mid_nl_up;
         view.lv.assign(p->lv.begin() + l, p->lv.end());

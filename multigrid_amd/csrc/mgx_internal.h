@@ -141,9 +141,8 @@ struct MidArgs {
     int ndown = 0, nup = 0;
     double omega = 0, nomega = 0;
     // filled by the launcher: tile a workgroup owns (rows x columns of the output level),
-    // tiles per axis, doubles per LDS array, position of each level's right-hand side in LDS
+    // tiles per axis, doubles per LDS array
     int tile_i = 0, tile_j = 0, nti = 0, ntj = 0, stride = 0;
-    int foff[MID_MAX_LEVELS] = {0};
 };
 // whether a launch for these levels and sweep counts exists (odd nested sizes, tiles that fit LDS)
 bool mid_fits(bool down, const MidArgs &A);

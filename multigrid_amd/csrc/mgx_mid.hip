@@ -46,7 +46,8 @@ namespace mgx {
 
 namespace {
 
-constexpr int MID_Q = 4;  // columns per thread the up kernel prefetches per level
+// Q, a template parameter of the kernels below: the points of a level a thread handles at
+// most (its registers hold their right-hand side, iterate and neighbours)
 
 struct Span {
     int lo, hi;  // inclusive
@@ -111,21 +112,33 @@ struct Lay {
 __device__ __forceinline__ Lay lay_of(const Span &si, const Span &sj) { return Lay{si.lo - 1, sj.lo - 1, width(si) + 2}; }
 __device__ __forceinline__ int at(const Lay &L, int i, int j) { return (i - L.i0) + (j - L.j0) * L.ld; }
 
-// Which points of a region a thread handles: lanes run along i (16, 32 or 64 of them per
-// column, whatever covers the region's width), the rest of the thread index along j.
-struct Walk {
-    int i, j, di, dj;
+// The points of a region a thread is responsible for: (i, j + q*dj), q < Q.  Lanes run
+// along i (16, 32 or 64 of them per column, whatever covers the region's width), the rest
+// of the thread index along j; the launcher sizes the tiles so that Q passes cover the
+// region.  The thread keeps f and the iterate at its points in registers from phase to
+// phase; LDS only carries the iterate to the neighbours.
+struct Pts {
+    int i, j, dj, jhi;  // grid indices of point 0, column step, last column of the region
+    int x, xs;          // LDS index of point 0 and its step per q
+    bool in_i;
+    __device__ __forceinline__ bool ok(int q) const { return in_i && j + q * dj <= jhi; }
+    __device__ __forceinline__ int col(int q) const { return j + q * dj; }
 };
-__device__ __forceinline__ Walk walk_of(const Span &si, const Span &sj)
+__device__ __forceinline__ Pts pts_of(const Span &si, const Span &sj, const Lay &L)
 {
     const int wx = width(si);
     const int lw = wx <= 16 ? 4 : (wx <= 32 ? 5 : 6);
     const int t = (int)threadIdx.x;
-    return Walk{si.lo + (t & ((1 << lw) - 1)), sj.lo + (t >> lw), 1 << lw, (int)blockDim.x >> lw};
+    Pts P;
+    P.i = si.lo + (t & ((1 << lw) - 1));
+    P.j = sj.lo + (t >> lw);
+    P.dj = (int)blockDim.x >> lw;
+    P.jhi = sj.hi;
+    P.in_i = P.i <= si.hi;
+    P.x = at(L, P.i, P.j);
+    P.xs = P.dj * L.ld;
+    return P;
 }
-#define MID_FOR(w_, si_, sj_, i_, j_)                              \
-    for (int j_ = (w_).j; j_ <= (sj_).hi; j_ += (w_).dj)          \
-        for (int i_ = (w_).i; i_ <= (si_).hi; i_ += (w_).di)
 
 __device__ __forceinline__ void zero_border(double *U, double *W, const Span &sj, const Lay &L)
 {
@@ -144,19 +157,7 @@ __device__ __forceinline__ void zero_border(double *U, double *W, const Span &sj
     }
 }
 
-__device__ __forceinline__ double jacobi_at(const double *__restrict__ U, const double *__restrict__ F, int x, int ld,
-                                            const SweepCoef &c)
-{
-    double s = U[x - 1] + U[x + 1];  // main.cpp:194-195
-    s = s + U[x - ld];
-    s = s + U[x + ld];
-    s = s - F[x] * c.h2;
-    s = s * 0.25;
-    s = s * c.omega;
-    return U[x] * c.nomega + s;
-}
-
-// the same sweep applied to an iterate that is zero everywhere
+// a sweep applied to an iterate that is zero everywhere (main.cpp:194-195 with u = 0)
 __device__ __forceinline__ double jacobi_from_zero(double f, const SweepCoef &c)
 {
     double s = 0.0 + 0.0;
@@ -166,18 +167,6 @@ __device__ __forceinline__ double jacobi_from_zero(double f, const SweepCoef &c)
     s = s * 0.25;
     s = s * c.omega;
     return 0.0 * c.nomega + s;
-}
-
-__device__ __forceinline__ void mid_sweep(const double *__restrict__ F, const double *__restrict__ U,
-                                          double *__restrict__ O, const Span &si, const Span &sj, const Lay &L,
-                                          const Walk &w, const SweepCoef &c)
-{
-    MID_FOR(w, si, sj, i, j)
-    {
-        const int x = at(L, i, j);
-        O[x] = jacobi_at(U, F, x, L.ld, c);
-    }
-    __syncthreads();
 }
 
 // interpolated coarse value at fine point (i, j); C holds the coarse level in layout LC
@@ -201,89 +190,146 @@ __device__ __forceinline__ double prolong_at(const double *__restrict__ C, const
     return p;
 }
 
-template <int NL>
+// the four neighbours of every point of the thread, requested together so that their LDS
+// latencies overlap (points outside the region read cell (1, 1) and are ignored)
+template <int Q>
+struct Nbr {
+    double w[Q], e[Q], s[Q], n[Q];
+};
+template <int Q>
+__device__ __forceinline__ void read_neighbours(const double *__restrict__ U, const Pts &P, const Lay &L, Nbr<Q> &N)
+{
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int x = P.ok(q) ? P.x + q * P.xs : L.ld + 1;
+        N.w[q] = U[x - 1];
+        N.e[q] = U[x + 1];
+        N.s[q] = U[x - L.ld];
+        N.n[q] = U[x + L.ld];
+    }
+}
+
+// one sweep U -> O at the thread's points (main.cpp:194-195); with C, the coarse-grid
+// correction is added to the result (main.cpp:341)
+template <int Q>
+__device__ __forceinline__ void sweep_pts(const double *__restrict__ U, double *__restrict__ O, const Pts &P, const Lay &L,
+                                          const SweepCoef &c, const double (&f)[Q], double (&u)[Q],
+                                          const double *__restrict__ C, const Lay &LC)
+{
+    Nbr<Q> N;
+    read_neighbours(U, P, L, N);
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        if (P.ok(q)) {
+            double s = N.w[q] + N.e[q];
+            s = s + N.s[q];
+            s = s + N.n[q];
+            s = s - f[q] * c.h2;
+            s = s * 0.25;
+            s = s * c.omega;
+            double v = u[q] * c.nomega + s;
+            if (C) v = v + prolong_at(C, LC, P.i, P.col(q));
+            u[q] = v;
+            O[P.x + q * P.xs] = v;
+        }
+    }
+    __syncthreads();
+}
+
+template <int NL, int Q>
 __global__ __launch_bounds__(1024) void k_mid_down(const MidArgs A)
 {
     extern __shared__ __align__(16) double lds[];
-    double *F = lds;
-    double *U = lds + A.stride;
-    double *W = lds + 2 * A.stride;
+    double *U = lds;
+    double *W = lds + A.stride;
     Span ni[NL + 1], oi[NL + 1], nj[NL + 1], oj[NL + 1];
     down_spans<NL>(A, (int)blockIdx.x, A.tile_i, A.nti, ni, oi);
     down_spans<NL>(A, (int)blockIdx.y, A.tile_j, A.ntj, nj, oj);
+    double f[Q], u[Q];
+    {
+        const Lay L = lay_of(ni[0], nj[0]);
+        const Pts P = pts_of(ni[0], nj[0], L);
+        const double *__restrict__ g = A.f[0];
+        const size_t m0 = (size_t)A.m[0];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const bool ok = P.ok(q);
+            const int ic = ok ? P.i : ni[0].lo, jc = ok ? P.col(q) : nj[0].lo;
+            f[q] = g[(size_t)ic + (size_t)jc * m0];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NL; k++) {
         const Span si = ni[k], sj = nj[k];
         const Lay L = lay_of(si, sj);
-        const Walk w = walk_of(si, sj);
+        const Pts P = pts_of(si, sj, L);
         const SweepCoef c{A.h2[k], A.invh2[k], A.omega, A.nomega};
         zero_border(U, W, sj, L);
         // the first sweep from zero needs f at the point only (main.cpp:321)
-        if (k == 0) {
-            const double *__restrict__ g = A.f[0];
-            const size_t m0 = (size_t)A.m[0];
-            MID_FOR(w, si, sj, i, j)
-            {
-                const int x = at(L, i, j);
-                const double fv = g[(size_t)i + (size_t)j * m0];
-                F[x] = fv;
-                U[x] = A.ndown > 0 ? jacobi_from_zero(fv, c) : 0.0;
-            }
-        } else {
-            MID_FOR(w, si, sj, i, j)
-            {
-                const int x = at(L, i, j);
-                U[x] = A.ndown > 0 ? jacobi_from_zero(F[x], c) : 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            if (P.ok(q)) {
+                u[q] = A.ndown > 0 ? jacobi_from_zero(f[q], c) : 0.0;
+                U[P.x + q * P.xs] = u[q];
             }
         }
         __syncthreads();
         for (int s = 1; s < A.ndown; s++) {
-            mid_sweep(F, U, W, si, sj, L, w, c);
+            sweep_pts(U, W, P, L, c, f, u, nullptr, L);
             double *t = U;
             U = W;
             W = t;
         }
-        MID_FOR(w, si, sj, i, j)  // main.cpp:325
-        {
-            const int x = at(L, i, j);
-            double s = U[x - 1] + U[x + 1];  // main.cpp:277
-            s = s + U[x - L.ld];
-            s = s + U[x + L.ld];
-            s = s - U[x] * 4.0;
-            s = s * c.invh2;
-            W[x] = F[x] - s;
+        {  // main.cpp:325: the residual, into the idle array
+            Nbr<Q> N;
+            read_neighbours(U, P, L, N);
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                if (P.ok(q)) {
+                    double s = N.w[q] + N.e[q];  // main.cpp:277
+                    s = s + N.s[q];
+                    s = s + N.n[q];
+                    s = s - u[q] * 4.0;
+                    s = s * c.invh2;
+                    W[P.x + q * P.xs] = f[q] - s;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        // main.cpp:327; the next level's f takes the place of this level's, which is spent
+        // main.cpp:327: every thread restricts at ITS points of the next level, whose
+        // right-hand side therefore never leaves the registers
         const Span ci = ni[k + 1], cj = nj[k + 1];
         const Lay LC = lay_of(ci, cj);
-        const Walk wc = walk_of(ci, cj);
+        const Pts PC = pts_of(ci, cj, LC);
         double *__restrict__ go = A.fo[k + 1];
         const size_t mc = (size_t)A.m[k + 1];
         const double *__restrict__ r = W;
         const int ld = L.ld;
-        MID_FOR(wc, ci, cj, I, J)
-        {
-            const int x = at(L, 2 * I, 2 * J);
-            const double a = r[x] * 0.25;  // main.cpp:216-218, corner quirk included
-            double nb = r[x - 1] + r[x + 1];
-            nb = nb + r[x - ld];
-            nb = nb + r[x + ld];
-            nb = nb * 0.125;
-            double cn = r[x - 1 - ld] + r[x + 1 - ld];
-            cn = cn + r[x + 1 - ld];
-            cn = cn + r[x + 1 + ld];
-            cn = cn * 0.0625;
-            const double val = (a + nb) + cn;
-            if (k + 1 < NL) F[at(LC, I, J)] = val;
-            if (I >= oi[k + 1].lo && I <= oi[k + 1].hi && J >= oj[k + 1].lo && J <= oj[k + 1].hi)
-                go[(size_t)I + (size_t)J * mc] = val;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            if (PC.ok(q)) {
+                const int I = PC.i, J = PC.col(q);
+                const int x = at(L, 2 * I, 2 * J);
+                const double a = r[x] * 0.25;  // main.cpp:216-218, corner quirk included
+                double nb = r[x - 1] + r[x + 1];
+                nb = nb + r[x - ld];
+                nb = nb + r[x + ld];
+                nb = nb * 0.125;
+                double cn = r[x - 1 - ld] + r[x + 1 - ld];
+                cn = cn + r[x + 1 - ld];
+                cn = cn + r[x + 1 + ld];
+                cn = cn * 0.0625;
+                const double val = (a + nb) + cn;
+                f[q] = val;
+                if (I >= oi[k + 1].lo && I <= oi[k + 1].hi && J >= oj[k + 1].lo && J <= oj[k + 1].hi)
+                    go[(size_t)I + (size_t)J * mc] = val;
+            }
         }
-        __syncthreads();
+        if (k + 1 < NL) __syncthreads();  // the residual is spent: its array serves the next level
     }
 }
 
-template <int NL>
+template <int NL, int Q>
 __global__ __launch_bounds__(1024) void k_mid_up(const MidArgs A)
 {
     extern __shared__ __align__(16) double lds[];
@@ -295,92 +341,68 @@ __global__ __launch_bounds__(1024) void k_mid_up(const MidArgs A)
     up_spans<NL>(A, (int)blockIdx.y, A.tile_j, A.ntj, gj, clj, ownj);
 
     // Everything the workgroup reads from memory is requested before anything is used, so
-    // that the levels' load latencies overlap: each thread holds at most MID_Q values per
-    // level (the launcher sizes the tiles for that).
-    double pf[NL][MID_Q], pc[MID_Q];
+    // that the levels' load latencies overlap; the right-hand sides stay in registers.
+    double pf[NL][Q], pc[Q];
 #pragma unroll
     for (int k = 0; k < NL; k++) {
-        const Walk w = walk_of(gi[k], gj[k]);
+        const Lay L = lay_of(gi[k], gj[k]);
+        const Pts P = pts_of(gi[k], gj[k], L);
         const double *__restrict__ g = A.f[k];
         const size_t mk = (size_t)A.m[k];
 #pragma unroll
-        for (int q = 0; q < MID_Q; q++) {
-            const int j = w.j + q * w.dj;
-            const bool ok = w.i <= gi[k].hi && j <= gj[k].hi;
-            const int ic = ok ? w.i : gi[k].lo, jc = ok ? j : gj[k].lo;
+        for (int q = 0; q < Q; q++) {
+            const bool ok = P.ok(q);
+            const int ic = ok ? P.i : gi[k].lo, jc = ok ? P.col(q) : gj[k].lo;
             pf[k][q] = g[(size_t)ic + (size_t)jc * mk];
         }
     }
+    // level NL in the layout of its interior points: boundary values land in the border
+    const Span cii{imax(1, cli.lo), imin(A.m[NL] - 2, cli.hi)};
+    const Span cjj{imax(1, clj.lo), imin(A.m[NL] - 2, clj.hi)};
+    Lay LC = lay_of(cii, cjj);
     {
-        const Walk w = walk_of(cli, clj);
+        const Pts P = pts_of(cli, clj, LC);
         const double *__restrict__ g = A.cv;
         const size_t mk = (size_t)A.m[NL];
 #pragma unroll
-        for (int q = 0; q < MID_Q; q++) {
-            const int j = w.j + q * w.dj;
-            const bool ok = w.i <= cli.hi && j <= clj.hi;
-            const int ic = ok ? w.i : cli.lo, jc = ok ? j : clj.lo;
+        for (int q = 0; q < Q; q++) {
+            const bool ok = P.ok(q);
+            const int ic = ok ? P.i : cli.lo, jc = ok ? P.col(q) : clj.lo;
             pc[q] = g[(size_t)ic + (size_t)jc * mk];
         }
-    }
 #pragma unroll
-    for (int k = 0; k < NL; k++) {
-        const Walk w = walk_of(gi[k], gj[k]);
-        const Lay L = lay_of(gi[k], gj[k]);
-        double *__restrict__ Fk = lds + A.foff[k];
-#pragma unroll
-        for (int q = 0; q < MID_Q; q++) {
-            const int j = w.j + q * w.dj;
-            if (w.i <= gi[k].hi && j <= gj[k].hi) Fk[at(L, w.i, j)] = pf[k][q];
-        }
-    }
-    // level NL in the layout of its interior points: boundary values land in the border
-    Lay LC;
-    {
-        const Span ii{imax(1, cli.lo), imin(A.m[NL] - 2, cli.hi)};
-        const Span jj{imax(1, clj.lo), imin(A.m[NL] - 2, clj.hi)};
-        LC = lay_of(ii, jj);
-        const Walk w = walk_of(cli, clj);
-#pragma unroll
-        for (int q = 0; q < MID_Q; q++) {
-            const int j = w.j + q * w.dj;
-            if (w.i <= cli.hi && j <= clj.hi) C[at(LC, w.i, j)] = pc[q];
-        }
+        for (int q = 0; q < Q; q++)
+            if (P.ok(q)) C[P.x + q * P.xs] = pc[q];
     }
 
+    double u[Q];
 #pragma unroll
     for (int k = NL - 1; k >= 0; k--) {
         const Span si = gi[k], sj = gj[k];
         const Lay L = lay_of(si, sj);
-        const Walk w = walk_of(si, sj);
+        const Pts P = pts_of(si, sj, L);
         const SweepCoef c{A.h2[k], A.invh2[k], A.omega, A.nomega};
-        const double *__restrict__ Fk = lds + A.foff[k];
         zero_border(U, W, sj, L);
         if (k == NL - 1) __syncthreads();  // the coarse values are in place
         // first sweep from zero (pointwise); with Ndown <= 1 the correction follows at once
-        MID_FOR(w, si, sj, i, j)
-        {
-            const int x = at(L, i, j);
-            double v = A.ndown > 0 ? jacobi_from_zero(Fk[x], c) : 0.0;
-            if (A.ndown <= 1) v = v + prolong_at(C, LC, i, j);  // main.cpp:341
-            U[x] = v;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            if (P.ok(q)) {
+                double v = A.ndown > 0 ? jacobi_from_zero(pf[k][q], c) : 0.0;
+                if (A.ndown <= 1) v = v + prolong_at(C, LC, P.i, P.col(q));  // main.cpp:341
+                u[q] = v;
+                U[P.x + q * P.xs] = v;
+            }
         }
         __syncthreads();
         for (int s = 2; s <= A.ndown; s++) {
-            MID_FOR(w, si, sj, i, j)
-            {
-                const int x = at(L, i, j);
-                double v = jacobi_at(U, Fk, x, L.ld, c);
-                if (s == A.ndown) v = v + prolong_at(C, LC, i, j);  // main.cpp:341
-                W[x] = v;
-            }
-            __syncthreads();
+            sweep_pts(U, W, P, L, c, pf[k], u, s == A.ndown ? C : nullptr, LC);
             double *t = U;
             U = W;
             W = t;
         }
         for (int s = 0; s < A.nup; s++) {  // main.cpp:343
-            mid_sweep(Fk, U, W, si, sj, L, w, c);
+            sweep_pts(U, W, P, L, c, pf[k], u, nullptr, LC);
             double *t = U;
             U = W;
             W = t;
@@ -390,12 +412,16 @@ __global__ __launch_bounds__(1024) void k_mid_up(const MidArgs A)
         C = U;
         U = t;
         LC = L;
-    }
-    {
-        const Walk w = walk_of(owni, ownj);
-        double *__restrict__ g = A.v;
-        const size_t m0 = (size_t)A.m[0];
-        MID_FOR(w, owni, ownj, i, j) g[(size_t)i + (size_t)j * m0] = C[at(LC, i, j)];
+        if (k == 0) {  // the thread's points of level 0 that lie in the tile
+            double *__restrict__ g = A.v;
+            const size_t m0 = (size_t)A.m[0];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int j = P.col(q);
+                if (P.ok(q) && P.i >= owni.lo && P.i <= owni.hi && j >= ownj.lo && j <= ownj.hi)
+                    g[(size_t)P.i + (size_t)j * m0] = u[q];
+            }
+        }
     }
 }
 
@@ -407,13 +433,20 @@ int env_int(const char *name, int dflt)
     return e && *e ? atoi(e) : dflt;
 }
 
-// threads per workgroup: the down kernel's workgroups are few and big, the up kernel's are
-// many and should all be resident at once (two or three per CU)
-int mid_threads(bool down)
+// Threads per workgroup and points per thread.  The kernels are bound by the latency of
+// their chain of phases, not by throughput: workgroups should all be resident at once.
+struct Config {
+    int threads, q;
+};
+Config mid_config(bool down, const MidArgs &A)
 {
-    int t = env_int(down ? "MGX_MID_DOWN_THREADS" : "MGX_MID_UP_THREADS", down ? 1024 : 512);
-    t = (t / 64) * 64;
-    return t < 64 ? 64 : (t > 1024 ? 1024 : t);
+    // measured on MI355X (tools/mid_exp.sh): 1024 threads, except 512 for the up legs of a group
+    Config c{down || A.nl == 1 ? 1024 : 512, 2};
+    c.threads = env_int(down ? "MGX_MID_DOWN_THREADS" : "MGX_MID_UP_THREADS", c.threads);
+    c.q = env_int(down ? "MGX_MID_DOWN_Q" : "MGX_MID_UP_Q", c.q);
+    c.threads = imin(imax((c.threads / 64) * 64, 64), 1024);
+    c.q = c.q <= 1 ? 1 : (c.q <= 2 ? 2 : 4);
+    return c;
 }
 
 size_t mid_lds_budget()
@@ -425,9 +458,8 @@ int lanes_log2(int wx) { return wx <= 16 ? 4 : (wx <= 32 ? 5 : 6); }
 
 struct Shape {
     bool ok = false;
-    int threads = 0;
+    int threads = 0, q = 0;
     int tile_i = 0, tile_j = 0, nti = 0, ntj = 0, stride = 0;
-    int foff[MID_MAX_LEVELS] = {0};
     size_t bytes = 0;
 };
 
@@ -445,30 +477,38 @@ void down_widths(const MidArgs &A, int tile, int (&wmax)[NL + 1])
 }
 
 template <int NL>
-Shape down_try(const MidArgs &A, int ti, int tj)
+Shape down_try(const MidArgs &A, const Config &cf, int ti, int tj)
 {
     Shape S;
     int wi[NL + 1], wj[NL + 1];
     down_widths<NL>(A, ti, wi);
     down_widths<NL>(A, tj, wj);
     int stride = 0;
-    for (int k = 0; k < NL; k++) stride = imax(stride, (wi[k] + 2) * (wj[k] + 2));
+    bool fits = true;
+    S.threads = cf.threads;
+    S.q = cf.q;
+    for (int k = 0; k <= NL; k++) {
+        // one pass of lanes along i, at most q passes along j (the registers of a thread)
+        if (wi[k] > 64) fits = false;
+        const int dj = S.threads >> lanes_log2(wi[k]);
+        if ((wj[k] + dj - 1) / dj > S.q) fits = false;
+        if (k < NL) stride = imax(stride, (wi[k] + 2) * (wj[k] + 2));
+    }
     S.tile_i = ti;
     S.tile_j = tj;
     S.nti = (A.m[NL] - 2 + ti - 1) / ti;
     S.ntj = (A.m[NL] - 2 + tj - 1) / tj;
     S.stride = (stride + 1) & ~1;
-    S.bytes = 3 * (size_t)S.stride * sizeof(double);
-    S.threads = mid_threads(true);
-    S.ok = S.bytes <= mid_lds_budget() && S.nti <= 65535 && S.ntj <= 65535;
+    S.bytes = 2 * (size_t)S.stride * sizeof(double);
+    S.ok = fits && S.bytes <= mid_lds_budget() && S.nti <= 65535 && S.ntj <= 65535;
     return S;
 }
 
 template <int NL>
-Shape down_shape(const MidArgs &A)
+Shape down_shape(const MidArgs &A, const Config &cf)
 {
     const int fi = env_int("MGX_MID_DOWN_TI", 0), fj = env_int("MGX_MID_DOWN_TJ", 0);
-    if (fi > 0 && fj > 0) return down_try<NL>(A, fi, fj);
+    if (fi > 0 && fj > 0) return down_try<NL>(A, cf, fi, fj);
     const int n = A.m[NL] - 2;
     // lanes run along i: the widest tile whose level-0 region still fits 64 lanes
     int ti = 1;
@@ -482,7 +522,7 @@ Shape down_shape(const MidArgs &A)
     }
     Shape best;
     for (int tj = imin(n, ti); tj >= 1; tj--) {
-        Shape S = down_try<NL>(A, ti, tj);
+        Shape S = down_try<NL>(A, cf, ti, tj);
         if (!S.ok) continue;
         best = S;
         // enough workgroups for every CU, as long as the tiles stay reasonably square
@@ -505,20 +545,21 @@ void up_widths(const MidArgs &A, int tile, int (&wmax)[NL + 1])
 }
 
 template <int NL>
-Shape up_try(const MidArgs &A, int ti, int tj)
+Shape up_try(const MidArgs &A, const Config &cf, int ti, int tj)
 {
     Shape S;
     int wi[NL + 1], wj[NL + 1];
     up_widths<NL>(A, ti, wi);
     up_widths<NL>(A, tj, wj);
-    bool fits = true;
+    bool fits = !(NL == 5 && cf.q == 4);  // that instance does not fit the registers of 1024 threads
     int stride = 0;
-    S.threads = mid_threads(false);
+    S.threads = cf.threads;
+    S.q = cf.q;
     for (int k = 0; k <= NL; k++) {
-        // one pass of lanes along i, at most MID_Q passes along j (the prefetch registers)
+        // one pass of lanes along i, at most q passes along j (the registers of a thread)
         if (wi[k] > 64) fits = false;
         const int dj = S.threads >> lanes_log2(wi[k]);
-        if ((wj[k] + dj - 1) / dj > MID_Q) fits = false;
+        if ((wj[k] + dj - 1) / dj > S.q) fits = false;
         stride = imax(stride, (wi[k] + 2) * (wj[k] + 2));
     }
     S.tile_i = ti;
@@ -526,21 +567,16 @@ Shape up_try(const MidArgs &A, int ti, int tj)
     S.nti = (A.m[0] - 2 + ti - 1) / ti;
     S.ntj = (A.m[0] - 2 + tj - 1) / tj;
     S.stride = (stride + 1) & ~1;
-    int off = 3 * S.stride;
-    for (int k = 0; k < NL; k++) {
-        S.foff[k] = off;
-        off += ((wi[k] + 2) * (wj[k] + 2) + 1) & ~1;
-    }
-    S.bytes = (size_t)off * sizeof(double);
+    S.bytes = 3 * (size_t)S.stride * sizeof(double);
     S.ok = fits && S.bytes <= mid_lds_budget() && S.nti <= 65535 && S.ntj <= 65535;
     return S;
 }
 
 template <int NL>
-Shape up_shape(const MidArgs &A)
+Shape up_shape(const MidArgs &A, const Config &cf)
 {
     const int fi = env_int("MGX_MID_UP_TI", 0), fj = env_int("MGX_MID_UP_TJ", 0);
-    if (fi > 0 && fj > 0) return up_try<NL>(A, fi, fj);
+    if (fi > 0 && fj > 0) return up_try<NL>(A, cf, fi, fj);
     const int n = A.m[0] - 2;
     int ti = 1;
     for (int t = imin(n, 64); t >= 1; t--) {
@@ -553,7 +589,7 @@ Shape up_shape(const MidArgs &A)
     }
     Shape best;
     for (int tj = imin(n, ti); tj >= 1; tj--) {
-        Shape S = up_try<NL>(A, ti, tj);
+        Shape S = up_try<NL>(A, cf, ti, tj);
         if (!S.ok) continue;
         best = S;
         if ((long)S.nti * S.ntj >= 512 || tj <= 8) break;
@@ -563,20 +599,21 @@ Shape up_shape(const MidArgs &A)
 
 // shapes are a function of the level sizes and the sweep counts: looked up per launch
 // (plus the tile sizes forced through the environment, which experiments change between plans)
-// down/up, levels, rows of level 0, Ndown, Nup, forced tile, LDS budget and threads
-using Key = std::tuple<int, int, int, int, int, int, int, int>;
+// down/up, levels, rows of level 0, Ndown, Nup, forced tile, LDS budget, threads and points per thread
+using Key = std::tuple<int, int, int, int, int, int, int, int, int>;
 std::mutex g_mu;
 std::map<Key, Shape> g_shapes;
 
 template <int NL>
 Shape shape_of(bool down, const MidArgs &A)
 {
+    const Config cf = mid_config(down, A);
     const Key key{down ? 0 : 1, NL, A.m[0], A.ndown, A.nup, env_int(down ? "MGX_MID_DOWN_TI" : "MGX_MID_UP_TI", 0),
-                  env_int(down ? "MGX_MID_DOWN_TJ" : "MGX_MID_UP_TJ", 0), (int)(mid_lds_budget() >> 10) * 2048 + mid_threads(down)};
+                  env_int(down ? "MGX_MID_DOWN_TJ" : "MGX_MID_UP_TJ", 0), (int)(mid_lds_budget() >> 10), cf.threads * 8 + cf.q};
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_shapes.find(key);
     if (it != g_shapes.end()) return it->second;
-    const Shape S = down ? down_shape<NL>(A) : up_shape<NL>(A);
+    const Shape S = down ? down_shape<NL>(A, cf) : up_shape<NL>(A, cf);
     g_shapes.emplace(key, S);
     return S;
 }
@@ -604,38 +641,61 @@ bool levels_nest(const MidArgs &A)
 }
 
 // a launch with more than 64 KB of dynamic LDS must be allowed once per kernel and device
-hipError_t allow_lds(const void *kernel, int slot, size_t bytes)
+hipError_t allow_lds(const void *kernel, size_t bytes)
 {
     static std::mutex mu;
-    static unsigned long long done[2 * (MID_MAX_LEVELS + 1)] = {0};
+    static std::map<const void *, unsigned long long> done;
     if (bytes <= 64 * 1024) return hipSuccess;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
     std::lock_guard<std::mutex> lock(mu);
-    if (done[slot] & bit) return hipSuccess;
+    unsigned long long &mask = done[kernel];
+    if (mask & bit) return hipSuccess;
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) done[slot] |= bit;
+    if (e == hipSuccess) mask |= bit;
     return e;
+}
+
+template <int NL, int Q>
+hipError_t launch_down_nq(const MidArgs &A, const Shape &S, hipStream_t s)
+{
+    hipError_t e = allow_lds((const void *)k_mid_down<NL, Q>, S.bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_mid_down<NL, Q>), dim3((unsigned)S.nti, (unsigned)S.ntj), dim3((unsigned)S.threads), S.bytes, s, A);
+    return hipGetLastError();
+}
+
+template <int NL, int Q>
+hipError_t launch_up_nq(const MidArgs &A, const Shape &S, hipStream_t s)
+{
+    hipError_t e = allow_lds((const void *)k_mid_up<NL, Q>, S.bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_mid_up<NL, Q>), dim3((unsigned)S.nti, (unsigned)S.ntj), dim3((unsigned)S.threads), S.bytes, s, A);
+    return hipGetLastError();
 }
 
 template <int NL>
 hipError_t launch_down_n(const MidArgs &A, const Shape &S, hipStream_t s)
 {
-    hipError_t e = allow_lds((const void *)k_mid_down<NL>, NL, S.bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_mid_down<NL>), dim3((unsigned)S.nti, (unsigned)S.ntj), dim3((unsigned)S.threads), S.bytes, s, A);
-    return hipGetLastError();
+    switch (S.q) {
+    case 1: return launch_down_nq<NL, 1>(A, S, s);
+    case 2: return launch_down_nq<NL, 2>(A, S, s);
+    case 4: return launch_down_nq<NL, 4>(A, S, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int NL>
 hipError_t launch_up_n(const MidArgs &A, const Shape &S, hipStream_t s)
 {
-    hipError_t e = allow_lds((const void *)k_mid_up<NL>, MID_MAX_LEVELS + 1 + NL, S.bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_mid_up<NL>), dim3((unsigned)S.nti, (unsigned)S.ntj), dim3((unsigned)S.threads), S.bytes, s, A);
-    return hipGetLastError();
+    switch (S.q) {
+    case 1: return launch_up_nq<NL, 1>(A, S, s);
+    case 2: return launch_up_nq<NL, 2>(A, S, s);
+    case 4: return launch_up_nq<NL, 4>(A, S, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 MidArgs with_shape(const MidArgs &A0, const Shape &S)
@@ -646,7 +706,6 @@ MidArgs with_shape(const MidArgs &A0, const Shape &S)
     A.nti = S.nti;
     A.ntj = S.ntj;
     A.stride = S.stride;
-    for (int k = 0; k < MID_MAX_LEVELS; k++) A.foff[k] = S.foff[k];
     return A;
 }
 

@@ -11,7 +11,8 @@ from conftest import assert_bits
 pytestmark = pytest.mark.gpu
 
 KNOBS = ("MGX_NO_MID", "MGX_NO_TAIL", "MGX_MID_MAX_M", "MGX_MID_DOWN_NL", "MGX_MID_UP_NL",
-         "MGX_MID_DOWN_TI", "MGX_MID_DOWN_TJ", "MGX_MID_UP_TI", "MGX_MID_UP_TJ", "MGX_MID_LDS_KB")
+         "MGX_MID_DOWN_TI", "MGX_MID_DOWN_TJ", "MGX_MID_UP_TI", "MGX_MID_UP_TJ", "MGX_MID_LDS_KB", "MGX_TAIL_SMALL_M", "MGX_MID_SINGLE_DOWN", "MGX_MID_SINGLE_UP",
+         "MGX_MID_UP_THREADS", "MGX_MID_DOWN_THREADS", "MGX_MID_UP_Q", "MGX_MID_DOWN_Q")
 
 
 def _problem(M, seed=0):
@@ -57,13 +58,19 @@ def test_default_groups_match_the_oracle(mg, O, monkeypatch, M, coarsest, nd, nu
     {"MGX_MID_DOWN_NL": 3, "MGX_MID_UP_NL": 5, "MGX_MID_MAX_M": 4097},
     {"MGX_MID_DOWN_NL": 4, "MGX_MID_UP_NL": 5, "MGX_NO_TAIL": 1, "MGX_MID_LDS_KB": 160},
     {"MGX_NO_TAIL": 1},
+    {"MGX_TAIL_SMALL_M": 65},
+    {"MGX_MID_SINGLE_DOWN": 0, "MGX_MID_SINGLE_UP": 0},
+    {"MGX_MID_SINGLE_DOWN": 2049, "MGX_MID_SINGLE_UP": 2049, "MGX_MID_UP_THREADS": 128, "MGX_MID_UP_Q": 4,
+     "MGX_MID_DOWN_THREADS": 256, "MGX_MID_DOWN_Q": 4},
+    {"MGX_MID_UP_THREADS": 1024, "MGX_MID_UP_Q": 1, "MGX_MID_DOWN_THREADS": 512, "MGX_MID_DOWN_Q": 1},
+    {"MGX_MID_UP_THREADS": 320, "MGX_MID_UP_Q": 4, "MGX_MID_DOWN_THREADS": 192, "MGX_MID_DOWN_Q": 2, "MGX_MID_MAX_M": 1025},
     {"MGX_MID_DOWN_TI": 3, "MGX_MID_DOWN_TJ": 5, "MGX_MID_UP_TI": 7, "MGX_MID_UP_TJ": 3},
     {"MGX_MID_DOWN_TI": 1, "MGX_MID_DOWN_TJ": 1, "MGX_MID_UP_TI": 1, "MGX_MID_UP_TJ": 1, "MGX_MID_MAX_M": 257},
     {"MGX_MID_DOWN_TI": 9, "MGX_MID_DOWN_TJ": 2, "MGX_MID_UP_TI": 50, "MGX_MID_UP_TJ": 11, "MGX_MID_MAX_M": 2049},
 ])
 @pytest.mark.parametrize("nd,nu", [(2, 2), (1, 1), (0, 3), (3, 0), (1, 2)])
 def test_every_grouping_and_tile_size_gives_the_same_bits(mg, O, monkeypatch, env, nd, nu):
-    M = 2049
+    M = 4097
     f, v0 = _problem(M, 1)
     dx = 1.0 / (M - 1)
     ref_sol, ref_rn, _ = O.multigrid(f, v0, dx, 2, nd, nu, 0.7, 2, omp=True)
