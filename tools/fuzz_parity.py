@@ -24,6 +24,9 @@ while time.time() < t_end:
         continue
     coarsest = int(rng.choice([1, 2, 2, 2, 3, 4, 6, 11, k, 2 * k]))
     nd, nu = int(rng.integers(0, 8)), int(rng.integers(0, 8))
+    if os.environ.get("FUZZ_LEAN"):  # the schedules with at most four sweeps per cycle (grouped launches, up+down fusion)
+        nd = int(rng.integers(0, 5))
+        nu = int(rng.integers(0, 5 - nd))
     omega = float(rng.choice([0.5, 0.6, 0.7, 0.8, 0.9, 1.0]))
     Nv = int(rng.integers(0, 5))
     sched = int(rng.choice([1, 2]))
@@ -52,7 +55,7 @@ while time.time() < t_end:
         continue
     if mode == 1 and M >= 65:  # the slab driver on one rank, V-cycles or full multigrid
         from multigrid_amd import slab
-        tail_m = int(rng.choice([17, 33, 65, 129]))
+        tail_m = int(rng.choice([17, 33, 65, 129, 257, 513]))
         use_fmg = bool(rng.integers(0, 2)) and not pj
         try:
             if use_fmg:
@@ -78,7 +81,7 @@ while time.time() < t_end:
         continue
     if mode in (3, 4) and M >= 65:  # the partitioned plan in one process: random slab count, split calls
         R = int(rng.integers(1, 9))
-        tail_m = int(rng.choice([17, 33, 65, 129]))
+        tail_m = int(rng.choice([17, 33, 65, 129, 257, 513]))
         use_fmg = bool(rng.integers(0, 3) == 0) and not pj
         try:
             if use_fmg:
