@@ -199,6 +199,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend)
+        # bring the communicator up with a collective before the first point-to-point batch
+        warm = torch.zeros(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(warm)
+        if backend == "nccl":
+            torch.cuda.synchronize()
 
     import multigrid_amd as mg
     from multigrid_amd import rhs
@@ -280,7 +285,8 @@ def main():
             bpp = algorithmic_bytes_per_point(kname, args.nd, args.nu)
             fbpp = fused_bytes_per_point(kname, args.nd, args.nu) or bpp
             achieved = fbpp * pts / avg_s / 1e9
-            prof_traffic, prof_src = PMC_TRAFFIC.get((kname, M, args.nd, args.nu), (None, None)) if world == 1 else (None, None)
+            whole_grid = world == 1 and not args.slab and args.mplan == 0  # the profiled launch is the single-plan one
+            prof_traffic, prof_src = PMC_TRAFFIC.get((kname, M, args.nd, args.nu), (None, None)) if whole_grid else (None, None)
             roof = {"bound": "hbm", "kernel": rocprof_kernel_name(kname, args.nd, args.nu),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None,
