@@ -386,6 +386,24 @@ int mgx_mplan_destroy(mgx_mplan *plan);
 int mgx_mplan_partition(int m, int coarsest, int nslabs, int tail_m, int *distributed_levels, int *bounds,
                         int bounds_len);
 int mgx_halo_plan(int distributed_levels, int Ndown, int Nup, int *Ev, int *Ef);
+/* Geometry of the grouped small-level launches (csrc/mgx_mid.hip), computed on the host (no
+ * GPU needed; no counterpart in the reference: it has one loop nest per operator and level).
+ * A launch takes nl consecutive levels, the finest with m0 rows; a workgroup owns a tile of
+ * the output level (down: level nl, up: level 0) and recomputes what the tile depends on.
+ * mgx_mid_shape: the tile, tiles per axis, threads and LDS bytes a launch would use (ok = 0:
+ * no such launch; the plan then runs the levels one by one).  mgx_mid_spans: along one axis,
+ * for tile t of `tile` points, inclusive index ranges lo[]/hi[] --
+ *   down: [k], k = 0..nl: points of level k whose right-hand side the workgroup holds;
+ *         [nl+1+k]: points of level k it writes (these partition the level);
+ *   up:   [k], k = 0..nl-1: points of level k it computes; [nl]: points of level nl it reads
+ *         (boundary included); [nl+1]: points of level 0 it writes.
+ * lo, hi: at least 2*(nl+1) entries each. */
+typedef struct mgx_mid_info {
+    int ok, threads, points_per_thread, tile_i, tile_j, ntiles_i, ntiles_j;
+    size_t lds_bytes;
+} mgx_mid_info;
+int mgx_mid_shape(int down, int nl, int m0, int Ndown, int Nup, mgx_mid_info *out);
+int mgx_mid_spans(int down, int nl, int m0, int Ndown, int Nup, int tile, int t, int *lo, int *hi);
 int mgx_mplan_nslabs(const mgx_mplan *plan);
 int mgx_mplan_depth(const mgx_mplan *plan);
 int mgx_mplan_distributed_levels(const mgx_mplan *plan); /* levels split over the slabs          */

@@ -44,6 +44,14 @@ class mgx_slab_info(ctypes.Structure):
     ]
 
 
+class mgx_mid_info(ctypes.Structure):
+    _fields_ = [
+        ("ok", ctypes.c_int), ("threads", ctypes.c_int), ("points_per_thread", ctypes.c_int),
+        ("tile_i", ctypes.c_int), ("tile_j", ctypes.c_int), ("ntiles_i", ctypes.c_int), ("ntiles_j", ctypes.c_int),
+        ("lds_bytes", ctypes.c_size_t),
+    ]
+
+
 class mgx_slab_op(ctypes.Structure):
     _fields_ = [
         ("struct_size", ctypes.c_int),
@@ -123,6 +131,10 @@ SIGNATURES = {
                                            ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "mgx_halo_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                      ctypes.POINTER(ctypes.c_int)]),
+    "mgx_mid_shape": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.POINTER(mgx_mid_info)]),
+    "mgx_mid_spans": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mgx_mplan_nslabs": (ctypes.c_int, [_vp]),
     "mgx_mplan_depth": (ctypes.c_int, [_vp]),
     "mgx_mplan_distributed_levels": (ctypes.c_int, [_vp]),

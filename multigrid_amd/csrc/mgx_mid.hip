@@ -34,6 +34,7 @@
 //
 // Expressions are those of mgx_kernels.hip / mgx_tail.hip, evaluated in the same
 // order: identical bits.
+#include "../../include/mgx.h"
 #include "mgx_internal.h"
 
 #include <map>
@@ -750,3 +751,94 @@ hipError_t launch_mid_up(const MidArgs &A0, hipStream_t s)
 }
 
 } // namespace mgx
+
+// ---- host-only introspection of the tiling (tests, tuning tools) ------------------------
+
+namespace {
+
+mgx::MidArgs geometry_args(int nl, int m0, int Ndown, int Nup)
+{
+    mgx::MidArgs A;
+    A.nl = nl;
+    int m = m0;
+    for (int k = 0; k <= nl && k <= mgx::MID_MAX_LEVELS; k++) {
+        A.m[k] = m;
+        m = (m + 1) / 2;
+    }
+    A.ndown = Ndown;
+    A.nup = Nup;
+    return A;
+}
+
+template <int NL>
+void spans_out(bool down, const mgx::MidArgs &A, int tile, int t, int *lo, int *hi)
+{
+    using namespace mgx;
+    if (down) {
+        const int nt = (A.m[NL] - 2 + tile - 1) / tile;
+        Span need[NL + 1], own[NL + 1];
+        down_spans<NL>(A, t, tile, nt, need, own);
+        for (int k = 0; k <= NL; k++) {
+            lo[k] = need[k].lo;
+            hi[k] = need[k].hi;
+            lo[NL + 1 + k] = own[k].lo;
+            hi[NL + 1 + k] = own[k].hi;
+        }
+    } else {
+        const int nt = (A.m[0] - 2 + tile - 1) / tile;
+        Span G[NL], cload, own;
+        up_spans<NL>(A, t, tile, nt, G, cload, own);
+        for (int k = 0; k < NL; k++) {
+            lo[k] = G[k].lo;
+            hi[k] = G[k].hi;
+        }
+        lo[NL] = cload.lo;
+        hi[NL] = cload.hi;
+        lo[NL + 1] = own.lo;
+        hi[NL + 1] = own.hi;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int mgx_mid_shape(int down, int nl, int m0, int Ndown, int Nup, mgx_mid_info *out)
+{
+    if (!out) return mgx::api_fail(MGX_ERR_ARG, "mgx_mid_shape: null result");
+    *out = mgx_mid_info();
+    if (nl < 1 || nl > mgx::MID_MAX_LEVELS || Ndown < 0 || Nup < 0) return mgx::api_fail(MGX_ERR_ARG, "mgx_mid_shape: bad argument");
+    const mgx::MidArgs A = geometry_args(nl, m0, Ndown, Nup);
+    if (!mgx::levels_nest(A)) return MGX_OK;  // out->ok stays 0
+    const mgx::Shape S = mgx::shape_any(down != 0, A);
+    out->ok = S.ok ? 1 : 0;
+    out->threads = S.threads;
+    out->points_per_thread = S.q;
+    out->tile_i = S.tile_i;
+    out->tile_j = S.tile_j;
+    out->ntiles_i = S.nti;
+    out->ntiles_j = S.ntj;
+    out->lds_bytes = S.bytes;
+    return MGX_OK;
+}
+
+int mgx_mid_spans(int down, int nl, int m0, int Ndown, int Nup, int tile, int t, int *lo, int *hi)
+{
+    if (!lo || !hi || nl < 1 || nl > mgx::MID_MAX_LEVELS || tile < 1 || Ndown < 0 || Nup < 0)
+        return mgx::api_fail(MGX_ERR_ARG, "mgx_mid_spans: bad argument");
+    const mgx::MidArgs A = geometry_args(nl, m0, Ndown, Nup);
+    if (!mgx::levels_nest(A)) return mgx::api_fail(MGX_ERR_HIERARCHY, "mgx_mid_spans: %d levels below %d rows do not nest", nl, m0);
+    const int n = (down ? A.m[nl] : A.m[0]) - 2;
+    if (t < 0 || t >= (n + tile - 1) / tile) return mgx::api_fail(MGX_ERR_ARG, "mgx_mid_spans: no tile %d", t);
+    switch (nl) {
+    case 1: spans_out<1>(down != 0, A, tile, t, lo, hi); break;
+    case 2: spans_out<2>(down != 0, A, tile, t, lo, hi); break;
+    case 3: spans_out<3>(down != 0, A, tile, t, lo, hi); break;
+    case 4: spans_out<4>(down != 0, A, tile, t, lo, hi); break;
+    case 5: spans_out<5>(down != 0, A, tile, t, lo, hi); break;
+    }
+    return MGX_OK;
+}
+
+} // extern "C"
+
