@@ -61,7 +61,9 @@ typedef struct mgx_options {
  *                        filled).  Only the boundary of v is then read from the host array,
  *                        which saves one of the three host<->device transfers of the call.
  *                        The result is the same bits; a wrong statement gives the solution
- *                        for the zero guess. */
+ *                        for the zero guess.  Without the flag a big guess (>= 64 MB) is
+ *                        looked at on the host while f uploads, and one whose interior is
+ *                        all +0.0 takes the same short cut; the flag saves the look. */
 #define MGX_FLAG_ZERO_GUESS 1
 
 #define MGX_SCHEDULE_DEFAULT 0

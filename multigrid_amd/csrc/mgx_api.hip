@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <future>
 #include <new>
 #include <utility>
 #include <vector>
@@ -1178,6 +1179,14 @@ int mgx_solve2d(const double *f, double *v, int m, int n, double dx,
     if (opt && opt->struct_size == (int)sizeof(mgx_options) && (opt->flags & MGX_FLAG_ZERO_GUESS)) {
         rc = mgx_plan_upload(p, f, nullptr);  // the interior of v is zero by the caller's word: not read
         if (!rc) rc = mgx_plan_upload_boundary(p, v);
+    } else if ((size_t)m * (size_t)m * sizeof(double) >= ((size_t)64 << 20)) {
+        // A big guess is usually zeros inside a boundary (main.cpp:420-439 passes exactly that).
+        // Host threads look while f is on its way up; if it is so, only the boundary follows,
+        // otherwise the array (a guess with data ends the look at once).
+        std::future<bool> zero = std::async(std::launch::async, host_interior_is_zero, v, m);
+        rc = mgx_plan_upload(p, f, nullptr);
+        const bool z = zero.get();
+        if (!rc) rc = z ? mgx_plan_upload_boundary(p, v) : mgx_plan_upload(p, nullptr, v);
     } else {
         rc = mgx_plan_upload(p, f, v);
     }

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -193,6 +194,31 @@ hipError_t host_to_device(double *dst_dev, const double *src_host, size_t count,
 hipError_t device_to_host(double *dst_host, const double *src_dev, size_t count, hipStream_t order)
 {
     return staged(false, const_cast<double *>(src_dev), dst_host, sizeof(double) * count, order);
+}
+
+// Whether every interior entry of an m x m column-major host array has all bits zero (+0.0;
+// a -0.0 counts as data).  Several threads, each over a block of columns; all of them stop at
+// the first non-zero any of them meets, so an array with data costs next to nothing.
+bool host_interior_is_zero(const double *v, int m)
+{
+    if (m < 3) return true;
+    const int T = io_threads();
+    std::atomic<bool> nonzero{false};
+    auto scan = [&](int t) {
+        const size_t ncol = (size_t)m - 2;
+        const size_t j0 = 1 + ncol * (size_t)t / (size_t)T, j1 = 1 + ncol * (size_t)(t + 1) / (size_t)T;
+        for (size_t j = j0; j < j1 && !nonzero.load(std::memory_order_relaxed); j++) {
+            const uint64_t *c = reinterpret_cast<const uint64_t *>(v + j * (size_t)m);
+            uint64_t acc = 0;
+            for (int i = 1; i < m - 1; i++) acc |= c[i];
+            if (acc) nonzero.store(true, std::memory_order_relaxed);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(scan, t);
+    scan(0);
+    for (std::thread &x : th) x.join();
+    return !nonzero.load();
 }
 
 } // namespace mgx

@@ -103,6 +103,8 @@ hipError_t launch_residual_norm(const double *u, const double *f, int m, int jlo
 // buffers (mgx_hostio.hip).  Synchronous; work already enqueued on `order` comes first.
 hipError_t host_to_device(double *dst_dev, const double *src_host, size_t count, hipStream_t order);
 hipError_t device_to_host(double *dst_host, const double *src_dev, size_t count, hipStream_t order);
+// every interior entry of the m x m host array is +0.0 (all bits zero); threaded, stops at the first that is not
+bool host_interior_is_zero(const double *v, int m);
 
 // ---- the LDS-resident bottom of the cycle (mgx_tail.hip) -----------------------
 static constexpr int TAIL_MAX_M = 65;

@@ -21,6 +21,7 @@
 #include "mgx_internal.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace mgx {
 
@@ -37,7 +38,7 @@ struct LevelView {
 
 // interior points (i, j), 1 <= i, j <= m-2, dealt over the workgroup
 #define MGX_TAIL_FOR_INTERIOR(m_, i_, j_)                                  \
-    for (int j_ = 1 + (int)(threadIdx.x >> 6); j_ < (m_)-1; j_ += 16)      \
+    for (int j_ = 1 + (int)(threadIdx.x >> 6); j_ < (m_)-1; j_ += (int)(blockDim.x >> 6)) \
         for (int i_ = 1 + (int)(threadIdx.x & 63); i_ < (m_)-1; i_ += 64)
 
 __device__ __forceinline__ void tail_sweep(LevelView &L, double omega, double nomega)
@@ -190,14 +191,14 @@ __global__ __launch_bounds__(1024) void k_tail(const TailArgs A)
 #pragma unroll
     for (int l = 0; l < TAIL_MAX_LEVELS; l++)
         if (l < A.nlev) total += 3 * A.m[l] * A.m[l];
-    for (int k = tid; k < total; k += 1024) lds[k] = 0.0;  // main.cpp:295-299
+    for (int k = tid; k < total; k += (int)blockDim.x) lds[k] = 0.0;  // main.cpp:295-299
     if (A.exact_tables)
-        for (int k = tid; k < A.tables_len; k += 1024) lds[A.tables_off + k] = A.exact_tables[k];
+        for (int k = tid; k < A.tables_len; k += (int)blockDim.x) lds[A.tables_off + k] = A.exact_tables[k];
     __syncthreads();
     LevelView L0 = tail_view<0>(A, lds, 0);
     {
         const int m0 = A.m[0];
-        for (int j = tid >> 6; j < m0; j += 16)
+        for (int j = tid >> 6; j < m0; j += (int)(blockDim.x >> 6))
             for (int i = tid & 63; i < m0; i += 64) L0.f[i + j * m0] = A.f[(size_t)i + (size_t)j * (size_t)A.ld];
     }
     __syncthreads();
@@ -243,7 +244,13 @@ hipError_t launch_tail(const TailArgs &A0, hipStream_t s)
         if (e != hipSuccess) return e;
         configured.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(k_tail, dim3(1), dim3(1024), bytes, s, A);
+    static const int threads = [] {
+        const char *e = getenv("MGX_TAIL_THREADS");
+        int t = e ? atoi(e) : 1024;
+        t = (t / 64) * 64;
+        return t < 64 ? 64 : (t > 1024 ? 1024 : t);
+    }();
+    hipLaunchKernelGGL(k_tail, dim3(1), dim3((unsigned)threads), bytes, s, A);
     return hipGetLastError();
 }
 

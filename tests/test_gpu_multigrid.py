@@ -301,3 +301,17 @@ def test_host_arrays_through_the_staged_transfers(mg, O):
     out = mg.solve_host(f, v, dx, 2, 2, 2, 0.6, 2, zero_guess=True)
     assert_bits(out.ResidualNorms, rn, "ResNorms, zero guess")
     assert_bits(v, sol, "Sol, zero guess")
+    # zero guess found by looking (no flag): same result; a single -0.0 or a value in the
+    # last interior entry makes it a guess with data, which is uploaded whole
+    v = vz.copy(order="F")
+    out = mg.solve_host(f, v, dx, 2, 2, 2, 0.6, 2)
+    assert_bits(out.ResidualNorms, rn, "ResNorms, zero guess detected")
+    assert_bits(v, sol, "Sol, zero guess detected")
+    for val in (-0.0, 0.25):
+        vd = vz.copy(order="F")
+        vd[m - 2, m - 2] = val
+        sol_d, rn_d, _ = O.multigrid(f, vd, dx, 1, 0, 1, 0.6, 2, omp=True)
+        v = vd.copy(order="F")
+        out = mg.solve_host(f, v, dx, 1, 0, 1, 0.6, 2)
+        assert_bits(out.ResidualNorms, rn_d, "ResNorms, guess with one entry %r" % val)
+        assert_bits(v, sol_d, "Sol, guess with one entry %r" % val)
