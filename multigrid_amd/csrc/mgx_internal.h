@@ -168,6 +168,7 @@ struct StreamArgs {
     int jfix_lo = -1, jfix_hi = -1;  // local index of the physical boundary columns j=0 / j=M-1, or -1
     int gf0 = 0, gc0 = 0;         // global column index of local column 0 (fine, coarse)
     int CJ = 0, nstrips = 0, nchunks = 0, nwv = 4;  // filled by the launcher
+    int remap = 0;                // filled by the launcher: renumbering of the workgroups over the XCDs (0: none)
     SweepCoef c;
 };
 static constexpr int STREAM_MAX_SWEEPS = 4;

@@ -412,14 +412,32 @@ template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
 __global__ __launch_bounds__(512) void k_stream(const StreamArgs A)
 {
     using G = Geo<NS, PA, NM, RES>;
-    const int strip = blockIdx.x * A.nwv + (threadIdx.x >> 6);  // A.nwv strips (waves) per workgroup
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (A.remap) {
+        // Workgroups are dealt to the 8 XCDs round-robin by linear id; they are renumbered so
+        // that one XCD (one L2) gets a contiguous run of the (strip group, chunk) plane, with
+        // neighbours along the strips -- which load the same halo rows at the same time --
+        // next to each other (MGX_XCD_REMAP=1, the default: level-0 launch -0.5 %, cycle
+        // -0.6 %; 2 = neighbours along the chunks: +10 %; 0 = none)
+        const int nsg = (int)gridDim.x, nch = (int)gridDim.y, N = nsg * nch;
+        const int id = bx + by * nsg, x = id & 7, q = N >> 3, r = N & 7;
+        const int L = x * q + (x < r ? x : r) + (id >> 3);
+        if (A.remap == 1) {
+            bx = L % nsg;
+            by = L / nsg;
+        } else {
+            by = L % nch;
+            bx = L / nch;
+        }
+    }
+    const int strip = bx * A.nwv + (threadIdx.x >> 6);  // A.nwv strips (waves) per workgroup
     if (strip >= A.nstrips) return;
     const int r0 = strip * G::S - G::PADLO;
     const bool edge = (r0 < 1) || (r0 + 127 > A.m - 2);
     if (edge)
-        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, true>(A, strip, (int)blockIdx.y);
+        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, true>(A, strip, by);
     else
-        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, false>(A, strip, (int)blockIdx.y);
+        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, false>(A, strip, by);
 }
 
 int env_int(const char *name, int dflt)
@@ -600,8 +618,10 @@ bool same_shape(const LaunchShape &a, const LaunchShape &b) { return a.nwv == b.
 template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
 hipError_t launch_shape(StreamArgs A, const LaunchShape &sh, int ncolsout, hipStream_t s)
 {
+    static const int remap = env_int("MGX_XCD_REMAP", 1);
     A.CJ = sh.CJ;
     A.nwv = sh.nwv;
+    A.remap = remap;
     A.nchunks = (ncolsout + sh.CJ - 1) / sh.CJ;
     const int nsg = (A.nstrips + sh.nwv - 1) / sh.nwv;
     hipLaunchKernelGGL((k_stream<NS, PA, NM, RES, ZERO_IN, STORE>), dim3((unsigned)nsg, (unsigned)A.nchunks),
