@@ -15,3 +15,8 @@ run MGX_CAP_WGS=1 MGX_CAP_LDS=65536 MGX_CAP_ROUNDS=6
 run MGX_CAP_CJ=256
 run MGX_CAP_CJ=128
 run MGX_CAP_ROUNDS=3 MGX_CAP_LDS=40000
+run MGX_CAP_WGS=4 MGX_CAP_LDS=36864
+run MGX_CAP_WGS=4 MGX_CAP_LDS=36864 MGX_CAP_ROUNDS=2
+run MGX_CAP_WGS=3 MGX_CAP_LDS=49152 MGX_CAP_ROUNDS=2
+run MGX_CAP_ROUNDS=5
+run MGX_XCD_REMAP=0
