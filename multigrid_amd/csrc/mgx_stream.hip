@@ -105,8 +105,27 @@ __device__ __forceinline__ double residual_pt(double uW, double uE, double uS, d
     return f - s;
 }
 
+// Neighbour lanes through the wavefront-wide DPP shifts of gfx9 (wave_shr:1 / wave_shl:1, two
+// VALU moves per double) instead of __shfl_up/__shfl_down (two ds_bpermute through the LDS
+// crossbar and a wait each); lanes 0 / 63 keep their own value, like the shuffles.
+#ifndef MGX_DPP_SHIFT
+#define MGX_DPP_SHIFT 1
+#endif
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#if MGX_DPP_SHIFT
+__device__ __forceinline__ double from_lower_lane(double v) { return dpp_shift<0x138>(v); }  // lane t-1 -> t
+__device__ __forceinline__ double from_upper_lane(double v) { return dpp_shift<0x130>(v); }  // lane t+1 -> t
+#else
 __device__ __forceinline__ double from_lower_lane(double v) { return __shfl_up(v, 1, 64); }    // lane t-1 -> t
 __device__ __forceinline__ double from_upper_lane(double v) { return __shfl_down(v, 1, 64); }  // lane t+1 -> t
+#endif
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
@@ -503,8 +522,9 @@ LaunchShape plain_shape(int nstrips, int ncolsout, int min_per_cu = 0, int min_c
 // Shape for a big launch that streams BOTH the iterate and the right-hand side (the
 // level-0 launches).  Two measured effects, 16385^2 V(2,2) up+down launch, 1.73 ms plain:
 //  * few resident waves: reserving 64 KB of (unused) LDS per workgroup leaves two
-//    workgroups per CU instead of six, and eight strips per workgroup instead of four
-//    share more halo rows inside a workgroup (1.73 -> 1.62 -> 1.56 ms);
+//    four-wave workgroups per CU instead of the three the kernel's ~150 VGPRs allow (8
+//    instead of 12 waves per CU), and eight strips per workgroup instead of four (one such
+//    workgroup per CU) share more halo rows inside a workgroup (1.73 -> 1.62 -> 1.56 ms);
 //  * whole rounds: capped workgroups run in rounds of 2 x #CUs, and a last round that is
 //    nearly empty wastes the chip, so the number of chunks is made a whole number of
 //    rounds (rounded down), at least three, with chunks of about 192 columns.
