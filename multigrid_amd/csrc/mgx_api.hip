@@ -95,6 +95,7 @@ struct mgx_plan {
     int mid_single_down_m = 1025, mid_single_up_m = 1025;  // MGX_MID_SINGLE_DOWN / MGX_MID_SINGLE_UP
     int tail_small_m = 33;  // a tail level above this size goes to a grouped launch where one exists (MGX_TAIL_SMALL_M)
     std::vector<Level> lv;
+    std::vector<void *> allocs;          // what hipMalloc returned (the level arrays may start inside)
     double *r = nullptr;                 // residual scratch of the stepwise schedule (fine size)
     unsigned long long *slots = nullptr; // encoded norms, one per cycle (+1)
     int nslots = 0;
@@ -133,10 +134,15 @@ struct DeviceScope {
     DeviceScope &operator=(const DeviceScope &) = delete;
 };
 
-int plan_alloc(mgx_plan *p, void **ptr, size_t nbytes)
+// `shift` bytes (a multiple of 256) are skipped at the start of the allocation: the arrays of a
+// level can be placed at different phases of the memory's channel interleave
+int plan_alloc(mgx_plan *p, void **ptr, size_t nbytes, size_t shift = 0)
 {
-    HIP_TRY(hipMalloc(ptr, nbytes));
-    p->bytes += nbytes;
+    void *raw = nullptr;
+    HIP_TRY(hipMalloc(&raw, nbytes + shift));
+    p->allocs.push_back(raw);
+    *ptr = (char *)raw + shift;
+    p->bytes += nbytes + shift;
     return MGX_OK;
 }
 
@@ -718,6 +724,19 @@ static int plan_create_on_device(mgx_plan **out, int m, double dx, int coarsest,
     if (const char *e = getenv("MGX_MID_DOWN_NL")) p->mid_nl_down = std::min(std::max(atoi(e), 1), MID_MAX_LEVELS);
     if (const char *e = getenv("MGX_MID_UP_NL")) p->mid_nl_up = std::min(std::max(atoi(e), 1), MID_MAX_LEVELS);
     p->lv.resize(depth + 1);
+    // The three arrays of a big level start at different phases of the memory's address
+    // interleave: allocations are aligned alike, so without this a launch reads v and f at
+    // the same phase at every moment.  Measured at 16385^2 (tools/stagger_sweep.sh): the
+    // level-0 up+down launch 1.523 -> 1.503 ms for any of a dozen offsets between 256 KB and
+    // 1.2 MB; MGX_STAGGER="bytes,bytes" (f, second iterate buffer) overrides, "0,0" = none.
+    size_t shift_f = 384 << 10, shift_v1 = 768 << 10;
+    if (const char *e = getenv("MGX_STAGGER")) {
+        long a = 0, b = 0;
+        if (sscanf(e, "%ld,%ld", &a, &b) == 2 && a >= 0 && b >= 0) {
+            shift_f = (size_t)a & ~(size_t)255;
+            shift_v1 = (size_t)b & ~(size_t)255;
+        }
+    }
     double h = dx;
     for (int d = 0; d <= depth; d++) {
         Level &L = p->lv[d];
@@ -725,9 +744,10 @@ static int plan_create_on_device(mgx_plan **out, int m, double dx, int coarsest,
         L.dx = h;
         h = h * 2.0;  // main.cpp:297
         const size_t nb = sizeof(double) * L.n();
-        rc = plan_alloc(p, (void **)&L.f, nb);
+        const bool big = nb >= ((size_t)32 << 20);
+        rc = plan_alloc(p, (void **)&L.f, nb, big ? shift_f : 0);
         if (!rc) rc = plan_alloc(p, (void **)&L.v[0], nb);
-        if (!rc) rc = plan_alloc(p, (void **)&L.v[1], nb);
+        if (!rc) rc = plan_alloc(p, (void **)&L.v[1], nb, big ? shift_v1 : 0);
         if (rc) { mgx_plan_destroy(p); return rc; }
         // main.cpp:295-299: every level starts as zeros
         hipError_t e = hipMemsetAsync(L.f, 0, nb, p->stream);
@@ -757,13 +777,7 @@ int mgx_plan_destroy(mgx_plan *p)
     DeviceScope on_plan_device(p);
     if (!p) return MGX_OK;
     (void)hipStreamSynchronize(p->stream);
-    for (Level &L : p->lv) {
-        if (L.f) (void)hipFree(L.f);
-        if (L.v[0]) (void)hipFree(L.v[0]);
-        if (L.v[1]) (void)hipFree(L.v[1]);
-    }
-    if (p->r) (void)hipFree(p->r);
-    if (p->exact_tables) (void)hipFree(p->exact_tables);
+    for (void *a : p->allocs) (void)hipFree(a);
     if (p->slots) (void)hipFree(p->slots);
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->evpool) (void)hipEventDestroy(e);
