@@ -726,9 +726,11 @@ static int plan_create_on_device(mgx_plan **out, int m, double dx, int coarsest,
     p->lv.resize(depth + 1);
     // The three arrays of a big level start at different phases of the memory's address
     // interleave: allocations are aligned alike, so without this a launch reads v and f at
-    // the same phase at every moment.  Measured at 16385^2 (tools/stagger_sweep.sh): the
-    // level-0 up+down launch 1.523 -> 1.503 ms for any of a dozen offsets between 256 KB and
-    // 1.2 MB; MGX_STAGGER="bytes,bytes" (f, second iterate buffer) overrides, "0,0" = none.
+    // the same phase at every moment.  Measured at 16385^2 (tools/stagger_sweep.sh): on two
+    // of three boxes the level-0 up+down launch went from 1.523-1.529 to 1.503-1.514 ms for
+    // any of a dozen offsets between 256 KB and 1.2 MB, on the third every placement,
+    // this one and none included, gave 1.504-1.519 ms: it removes a bad case, no more.
+    // MGX_STAGGER="bytes,bytes" (f, second iterate buffer) overrides, "0,0" = none.
     size_t shift_f = 384 << 10, shift_v1 = 768 << 10;
     if (const char *e = getenv("MGX_STAGGER")) {
         long a = 0, b = 0;
