@@ -17,13 +17,18 @@
 //       per level, coarse to fine: Ndown sweeps from zero, += P(coarse v),
 //       Nup sweeps (refine + `cur += refined` + relax, main.cpp:337-344)
 //
-// A workgroup owns a rectangular tile of the OUTPUT level and computes, in LDS,
-// every point of every level that its tile depends on (overlapping tiles
-// recompute their common points; Jacobi makes the copies bit-identical).  Going
-// down the dependence region roughly doubles per level (a tile of T coarse
-// points needs 2T + 2(Ndown+1) fine points), so down launches take two or three
-// levels; going up it converges (a tile of T fine points needs T/2 + ~4 coarse
-// points), so one up launch can take every level of the group.
+// A workgroup owns a rectangular tile of the OUTPUT level and computes every point
+// of every level that its tile depends on (overlapping tiles recompute their
+// common points; Jacobi makes the copies bit-identical).  Going down the
+// dependence region roughly doubles per level (a tile of T coarse points needs
+// 2T + 2(Ndown+1) fine points), so down launches take two levels; going up it
+// converges (a tile of T fine points needs T/2 + ~4 coarse points), so one up
+// launch can take every level of the group.  A thread keeps the right-hand side
+// and the iterate of its (at most Q) points of a level in registers from phase to
+// phase; LDS carries the iterate to the neighbours, one workgroup barrier per
+// sweep.  The kernels are bound by the latency of that chain of phases (about
+// 0.4 us each on MI355X), not by throughput: shapes are chosen so that every
+// workgroup of a launch is resident at once.
 //
 // LDS arrays hold a region with a one-cell border of zeros.  Where the region
 // touches the edge of the grid the border IS the boundary (zero: the iterate
@@ -46,9 +51,6 @@
 namespace mgx {
 
 namespace {
-
-// Q, a template parameter of the kernels below: the points of a level a thread handles at
-// most (its registers hold their right-hand side, iterate and neighbours)
 
 struct Span {
     int lo, hi;  // inclusive
