@@ -311,3 +311,26 @@ def test_cycles_to_a_tolerance_257(mg, O, known, f_smooth_257):
     out, why = plan.cycles_until(0, 2, 2, 0.6, 1e-8)
     assert why == _lib.STOP_MAX_CYCLES and out.ResidualNorms.shape == (1,)
     plan.close()
+
+
+def test_32769_host_arrays_against_the_threaded_oracle(mg, O):
+    """32769^2 (the full-multigrid configuration's size; 8.6 GB per array) through the entry
+    point the reference's main() would call, mgx_solve2d on ordinary host arrays: two V(2,2)
+    cycles from a zero guess with Dirichlet data, Sol and ResNorms bit-identical to the CPU
+    oracle's OpenMP build.  Covers the staged transfers, the zero-guess look and every kind of
+    launch of the schedule at four times the benchmark's points."""
+    import os
+    from multigrid_amd import rhs
+    host_gb = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 1e9
+    if _free_hbm_gb() < 50 or host_gb < 120:
+        pytest.skip("needs 50 GB of free HBM and 120 GB of host memory")
+    m = 32769
+    dx = 1.0 / (m - 1)
+    f = rhs.random_np(m)
+    v0 = np.zeros((m, m), order="F")
+    rng = np.random.default_rng(32769)
+    v0[0, :], v0[-1, :], v0[:, 0], v0[:, -1] = rng.standard_normal((4, m))
+    sol, rn, _ = O.multigrid(f, v0, dx, 2, 2, 2, 0.6, 2, omp=True)
+    out = mg.solve_host(f, v0, dx, 2, 2, 2, 0.6, 2)        # v0 is overwritten with the solution
+    assert_bits(out.ResidualNorms, rn, "ResNorms 32769")
+    assert np.array_equal(v0.view(np.uint64), sol.view(np.uint64)), "Sol 32769"
