@@ -65,8 +65,14 @@ class HipBackend:
         self.schedule = schedule
         self.coarse_solve = coarse_solve  # what the replicated tail does on the coarsest grid
 
-    def zeros(self, ncols, m):
-        return torch.zeros((ncols, m), dtype=torch.float64, device=self.device)
+    def zeros(self, ncols, m, phase=0):
+        """phase 1 / 2: a big array starts 384 / 768 KB into its allocation, so that the arrays a
+        launch streams side by side sit at different phases of the memory's address interleave
+        (allocations are aligned alike; what mgx_plan_create does for its levels)."""
+        shift = (phase * 384 * 1024) // 8 if ncols * m * 8 >= (32 << 20) else 0
+        if not shift:
+            return torch.zeros((ncols, m), dtype=torch.float64, device=self.device)
+        return torch.zeros(ncols * m + shift, dtype=torch.float64, device=self.device)[shift:].view(ncols, m)
 
     def slots(self, n):
         return torch.zeros(n, dtype=torch.int64, device=self.device)
@@ -420,8 +426,8 @@ class SlabSolver:
             Lv.jfix_hi = Lv.ncols - 1 if Lv.hi == dims[l] else -1
             if Lv.b1 - Lv.b0 < Lv.W and R > 1:
                 raise ValueError("rank %d owns %d < %d columns of level %d" % (g, Lv.b1 - Lv.b0, Lv.W, l))
-            Lv.f = self.be.zeros(Lv.ncols, Lv.m)
-            Lv.v = [self.be.zeros(Lv.ncols, Lv.m), self.be.zeros(Lv.ncols, Lv.m)]
+            Lv.f = self.be.zeros(Lv.ncols, Lv.m, phase=1)
+            Lv.v = [self.be.zeros(Lv.ncols, Lv.m), self.be.zeros(Lv.ncols, Lv.m, phase=2)]
             Lv.cur = 0
             self.levels.append(Lv)
         # the tail's top level: the coarse columns this rank produces, padded to a common count
@@ -460,8 +466,9 @@ class SlabSolver:
         directly on each GPU for its own columns."""
         from . import rhs
         L0 = self.levels[0]
-        L0.f = rhs.random_torch_cols(self.M, L0.lo, L0.hi, device=self.be.device)
-        L0.v = [self.be.zeros(L0.ncols, L0.m), self.be.zeros(L0.ncols, L0.m)]
+        L0.f.copy_(rhs.random_torch_cols(self.M, L0.lo, L0.hi, device=self.be.device))
+        L0.v[0].zero_()
+        L0.v[1].zero_()
         L0.cur = 0
 
     def owned_solution(self):

@@ -54,7 +54,7 @@ class NumpyBackend:
         self.O = oracle
         self.coarse_exact = coarse_exact
 
-    def zeros(self, ncols, m):
+    def zeros(self, ncols, m, phase=0):
         return np.zeros((ncols, m))
 
     def slots(self, n):
