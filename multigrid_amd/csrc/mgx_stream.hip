@@ -403,13 +403,14 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
 
     for (int jin = jstart; jin <= jlast; jin += 2) {
 #ifndef MGX_LOCKSTEP
-#define MGX_LOCKSTEP 32
+#define MGX_LOCKSTEP 8
 #endif
 #if MGX_LOCKSTEP > 0
         // Keep the workgroup's strips within MGX_LOCKSTEP columns of each
         // other, so that the halo rows two of them share are still in the XCD's
-        // L2 when the second wave reads them (measured: -2.4 % on the level-0
-        // launch).  All waves of a workgroup march the same chunk, hence the same
+        // L2 when the second wave reads them (measured on the level-0 launch: none
+        // 1.551 ms, every 64 columns 1.515, 32: 1.500, 16: 1.491, 8: 1.487, 4: 1.487,
+        // 2: 1.497).  All waves of a workgroup march the same chunk, hence the same
         // trip count; a wave that has exited is not waited for.
         if (((jin - jstart) & (MGX_LOCKSTEP - 1)) == 0) __builtin_amdgcn_s_barrier();
 #endif
