@@ -508,7 +508,12 @@ LaunchShape plain_shape(int nstrips, int ncolsout, int min_per_cu = 0, int min_c
     LaunchShape sh;
     const int nsg = (nstrips + sh.nwv - 1) / sh.nwv;
     sh.CJ = cj_max;
-    while (sh.CJ > cj_min && (long)nsg * ((ncolsout + sh.CJ - 1) / sh.CJ) < min_blocks) sh.CJ >>= 1;
+    while (sh.CJ > cj_min && (long)nsg * ((ncolsout + sh.CJ - 1) / sh.CJ) < min_blocks) {
+        // below 16 columns the halo columns of a chunk outweigh its own: not while half as
+        // many workgroups still cover the chip twice (2049^2: legs 26.4 + 19.1 -> 25.4 + 17.8 us)
+        if (sh.CJ <= 16 && 2L * nsg * ((ncolsout + sh.CJ - 1) / sh.CJ) >= min_blocks) break;
+        sh.CJ >>= 1;
+    }
     // A launch big enough for chunks of ~192 columns at two or more workgroups per CU gets
     // the same number of workgroups on every CU (all are resident at once): the chunk
     // count is rounded down to a multiple of #CUs / strip groups.  8193^2, V(2,2): up leg
