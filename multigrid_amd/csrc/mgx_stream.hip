@@ -549,11 +549,16 @@ LaunchShape plain_shape(int nstrips, int ncolsout, int min_per_cu = 0, int min_c
 // Launches that read only f (levels >= 1) and launches too small for chunks of 64
 // columns lose from the cap and keep the plain shape.  Defaults are the measured optimum
 // at 8193^2..32769^2; the environment variables exist for re-tuning.
-bool capped_shape(int nstrips, int ncolsout, LaunchShape &sh)
+// A second variant, chunks of about 256 columns in at least two rounds, is a candidate of its
+// own: at 16385^2 it wins (1.485 -> 1.473 ms, reads 19.2 -> 18.9 B/point), at 22529^2 and
+// 32769^2 it loses 1 %.
+bool capped_shape(int nstrips, int ncolsout, LaunchShape &sh, bool longer = false)
 {
-    static const int cap_lds = env_int("MGX_CAP_LDS", 65536), cap_cj = env_int("MGX_CAP_CJ", 192);
-    static const int cap_rounds = env_int("MGX_CAP_ROUNDS", 3), cap_wgs = env_int("MGX_CAP_WGS", 2);
+    static const int cap_lds = env_int("MGX_CAP_LDS", 65536), cap_cj0 = env_int("MGX_CAP_CJ", 192);
+    static const int cap_rounds0 = env_int("MGX_CAP_ROUNDS", 3), cap_wgs = env_int("MGX_CAP_WGS", 2);
     static const int cap_minblk = env_int("MGX_CAP_MINBLK", 512);
+    static const int cap_cj1 = env_int("MGX_CAP_CJ_LONG", 256), cap_rounds1 = env_int("MGX_CAP_ROUNDS_LONG", 2);
+    const int cap_cj = longer ? cap_cj1 : cap_cj0, cap_rounds = longer ? cap_rounds1 : cap_rounds0;
     const int ncu = cu_count();
     if (cap_lds <= 0 || cap_lds > 65536) return false;
     const long slots = (long)cap_wgs * ncu;
@@ -586,12 +591,12 @@ bool capped_shape(int nstrips, int ncolsout, LaunchShape &sh)
 // per geometry and process; after that nothing blocks.  MGX_TUNE=0 turns this off
 // (square-ish launches of at least 12000 columns then take the cap, others the plain shape).
 struct ShapeTuner {
-    static constexpr int MAXC = 3, WINDOW = 3;
+    static constexpr int MAXC = 4, WINDOW = 3;
     struct Entry {
         int device = -1, m = 0, ncols = 0;
         int ncand = 0;
         LaunchShape cand[MAXC];
-        float time[MAXC] = {0, 0, 0};
+        float time[MAXC] = {0, 0, 0, 0};
         int chosen = -1, cur = 0, count = -1;  // count -1: one untimed launch first (cold start)
         hipEvent_t e0[WINDOW] = {nullptr}, e1[WINDOW] = {nullptr};
     };
@@ -685,6 +690,8 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
         if (capped_shape(A.nstrips, ncolsout, capped)) {
             cands[ncands++] = capped;
             if (4L * ncolsout >= 3L * m && ncolsout >= 12000) std::swap(cands[0], cands[1]);  // a big square level
+            LaunchShape longer = plain;
+            if (capped_shape(A.nstrips, ncolsout, longer, true) && !same_shape(longer, capped)) cands[ncands++] = longer;
         }
         const LaunchShape wide = plain_shape(A.nstrips, ncolsout, 3, 60);
         if (!same_shape(wide, plain)) cands[ncands++] = wide;

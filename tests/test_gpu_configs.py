@@ -32,12 +32,12 @@ def test_4097_ten_cycles_against_the_oracle(mg, O, sched):
 def test_16385_against_the_threaded_oracle(mg, O):
     """The benchmark size and schedule, compared with the CPU oracle itself (its OpenMP build
     returns the same bits as the plain one, tests/test_oracle.py).  Every measured launch
-    shape is forgotten first and the run is long enough (12 cycles = 11 up+down launches)
+    shape is forgotten first and the run is long enough (15 cycles = 14 up+down launches: one untimed, three for each of four shapes)
     for each candidate shape of the level-0 launches to produce cycles of the compared
     result at exactly this geometry; a second plan, tuned on the spot, must agree too."""
     import torch
     from multigrid_amd import _lib, rhs
-    m, Nv = 16385, 12
+    m, Nv = 16385, 15
     dx = 1.0 / (m - 1)
     f = rhs.random_np(m)
     sol, rn, _ = O.multigrid(f, np.zeros((m, m), order="F"), dx, Nv, 2, 2, 0.6, 2, omp=True)

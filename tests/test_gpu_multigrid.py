@@ -271,7 +271,7 @@ def test_schedules_agree_at_large_sizes_that_are_not_powers_of_two(mg, k, d):
     res = []
     for sched in (mg.SCHEDULE_STEPWISE, mg.SCHEDULE_FUSED):
         prob = mg.gridtype(f, mg.colmajor(m, m), dx)
-        out = mg.MultiGrid(prob, 12, 2, 2, 0.6, k, schedule=sched)  # enough launches for every candidate shape
+        out = mg.MultiGrid(prob, 15, 2, 2, 0.6, k, schedule=sched)  # enough launches for every candidate shape
         res.append((out.ResidualNorms, prob.v))
     assert_bits(res[0][0], res[1][0], "ResNorms m=%d" % m)
     assert torch.equal(res[0][1].view(torch.int64), res[1][1].view(torch.int64))
