@@ -66,7 +66,7 @@ def fused_bytes_per_point(kernel, nd, nu):
 # corrections applied) for the default workload, measured in a SEPARATE profiled run of
 # this same command and kept with the round's profiles.  Reported as `traffic_profiled`
 # (never as `traffic`, which is reserved for something this run measured itself).
-PMC_TRAFFIC = {("k_stream:updown", 16385, 2, 2): (7.870e9, "profiles/r02_final_pmc_traffic.txt")}
+PMC_TRAFFIC = {("k_stream:updown", 16385, 2, 2): (7.784e9, "profiles/r02_final_pmc_traffic.txt")}
 
 
 def rocprof_kernel_name(kernel, nd, nu):

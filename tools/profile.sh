@@ -16,8 +16,8 @@ python3 profiles/per_launch.py $F > $OUT/per_launch.txt
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 cp $F $OUT/kernel_trace.csv
 rm -rf $OUT/trace
-MGX_TUNE=0 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > /dev/null 2> $OUT/pmc_fetch.err
-MGX_TUNE=0 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > /dev/null 2> $OUT/pmc_write.err
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > /dev/null 2> $OUT/pmc_fetch.err
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 bench.py --steps 3 --warmup 1 --cpu-baseline off > /dev/null 2> $OUT/pmc_write.err
 python3 profiles/pmc_summary.py $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1) $(find $OUT/pmc_write -name '*counter_collection.csv' | head -1) > $OUT/pmc_traffic.txt
 head -3 $(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1) > $OUT/pmc_csv_head.txt
 rm -rf $OUT/pmc_fetch $OUT/pmc_write
