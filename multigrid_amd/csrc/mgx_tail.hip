@@ -36,10 +36,13 @@ struct LevelView {
     double h2, invh2;
 };
 
-// interior points (i, j), 1 <= i, j <= m-2, dealt over the workgroup
-#define MGX_TAIL_FOR_INTERIOR(m_, i_, j_)                                  \
-    for (int j_ = 1 + (int)(threadIdx.x >> 6); j_ < (m_)-1; j_ += (int)(blockDim.x >> 6)) \
-        for (int i_ = 1 + (int)(threadIdx.x & 63); i_ < (m_)-1; i_ += 64)
+// interior points (i, j), 1 <= i, j <= m-2, dealt over the workgroup: 16, 32 or 64 lanes
+// along i, whatever covers a column, so that a 33x33 level takes one pass per phase, not two
+__device__ __forceinline__ int tail_lanes_log2(int m) { return m - 2 <= 16 ? 4 : (m - 2 <= 32 ? 5 : 6); }
+#define MGX_TAIL_FOR_INTERIOR(m_, i_, j_)                                                               \
+    for (int lw_ = tail_lanes_log2(m_), j_ = 1 + (int)(threadIdx.x >> lw_); j_ < (m_)-1;                \
+         j_ += (int)(blockDim.x >> lw_))                                                                \
+        for (int i_ = 1 + (int)(threadIdx.x & ((1u << lw_) - 1)); i_ < (m_)-1; i_ += (1 << lw_))
 
 __device__ __forceinline__ void tail_sweep(LevelView &L, double omega, double nomega)
 {
