@@ -149,6 +149,11 @@ def cpu_baseline_reference(M, nd, nu, omega, coarsest=2):
 
 
 def main():
+    # Libraries write to stdout too (RCCL prints a version banner when a communicator comes
+    # up): everything goes to stderr, except the one JSON line at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="V-cycles timed (the reference's default Nv is 100)")
@@ -331,7 +336,8 @@ def main():
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "DOF/s", "cores": 1, "kind": "port",
                                         "sample": "failed: %r" % (e,)}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
     if grouped:
         dist.barrier()
