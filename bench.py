@@ -148,6 +148,65 @@ def cpu_baseline_reference(M, nd, nu, omega, coarsest=2):
                       "-Ofast), %.1f s of which %.1f s inside relax() by its own Times" % (nd, nu, M, M, dt, float(tim[-1]))}
 
 
+def launch_ranks(n, out_fd):
+    """Start `n` ranks of this script as child processes (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1), pass rank 0's JSON
+    line on to `out_fd` and return the worst exit status.  The caller has initialised
+    neither torch nor the GPU, and nothing is exec'ed over a process that has."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    limit = float(os.environ.get("MGX_BENCH_TIMEOUT", "1500"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"WORLD_SIZE": str(n), "RANK": str(r), "LOCAL_RANK": str(r), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "MGX_BENCH_LAUNCHER": "self"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    t0 = time.time()
+    worst, failed_at = 0, None
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 128 - rc)
+                failed_at = failed_at or time.time()
+                sys.stderr.write("bench.py: rank %d ended with status %d\n" % (r, rc))
+        overdue = time.time() - t0 > limit
+        # a rank that failed leaves the others waiting in a collective: end them
+        if live and (overdue or (failed_at and time.time() - failed_at > 10)):
+            for r in live:
+                procs[r].send_signal(signal.SIGTERM)
+            time.sleep(5)
+            for r in live:
+                if procs[r].poll() is None:
+                    procs[r].kill()
+            worst = worst or 124
+            if overdue:
+                sys.stderr.write("bench.py: ranks still running after %.0f s were ended\n" % limit)
+            break
+        time.sleep(0.05)
+    text = procs[0].stdout.read()
+    for p in procs:
+        p.wait()
+    lines = [l for l in text.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        os.write(out_fd, (lines[-1] + "\n").encode())
+    elif worst == 0:
+        worst = 1
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+    return worst
+
+
 def main():
     # Libraries write to stdout too (RCCL prints a version banner when a communicator comes
     # up): everything goes to stderr, except the one JSON line at the end.
@@ -181,6 +240,11 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=0, help="grid size for the CPU baseline (0 = --size)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.mplan == 0:
+        # `python bench.py --gpus N` with no launcher around it: this process becomes the
+        # launcher.  It touches neither torch nor the GPU; the ranks are its children.
+        sys.exit(launch_ranks(args.gpus, real_stdout))
+
     import torch
     import torch.distributed as dist
 
@@ -188,8 +252,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
     # one GPU per rank; MGX_DIST_BACKEND=gloo rehearses the multi-rank path on a box
     # with fewer GPUs than ranks (ranks then share devices and stage halos on the host)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MGX_VERSION 200
+#define MGX_VERSION 210
 
 #define MGX_OK 0
 #define MGX_ERR_ARG (-1)      /* bad size / null pointer / non-square / even size   */
@@ -176,9 +176,10 @@ int mgx_plan_cycles(mgx_plan *plan, int Nv, int Ndown, int Nup, double omega, in
  * is a fixed number of cycles (main.cpp:309), so this is a loop AROUND mgx_plan_cycles(), not
  * a change of it.  Cycles run in batches of `batch`; after each batch the history is read and
  * the loop ends when some cycle's norm is at most rel_tol times the initial one
- * (MGX_STOP_TOLERANCE), when a cycle after the third no longer halves the norm
- * (MGX_STOP_FLOOR: in fp64 the residual f - Lap_h(u) cannot fall below about
- * eps * 8/h^2 * max|u|, which at 22529^2 is 4e-8 of a unit right-hand side), or after
+ * (MGX_STOP_TOLERANCE), when three cycles in a row fail to bring the norm 10 % below the
+ * smallest seen so far (MGX_STOP_FLOOR: in fp64 the residual f - Lap_h(u) cannot fall below about
+ * eps * 8/h^2 * max|u|, which at 22529^2 is 4e-8 of a unit right-hand side, and hovers
+ * there; a cycle that merely converges slowly is not a floor), or after
  * max_cycles (MGX_STOP_MAX_CYCLES).  The cycles of the last batch are all run: *cycles_done is a
  * multiple of `batch` (or max_cycles).  resnorms / times: max_cycles+1 entries, filled up to
  * *cycles_done; the same bits as one mgx_plan_cycles() call of *cycles_done cycles. */
@@ -219,6 +220,11 @@ int mgx_plan_fmg(mgx_plan *plan, int ncyc, int Ndown, int Nup, double omega, dou
 #define MGX_KERNEL_COUNT 8
 int mgx_plan_profile(mgx_plan *plan, int enable);
 int mgx_plan_profile_get(const mgx_plan *plan, int kernel_id, long *count, double *total_ms);
+/* enable = 2 brackets the launches of EVERY level (a few microseconds of event records per
+ * small launch: for a breakdown, not for a timed run); mgx_plan_profile_level() then gives, per
+ * level, the launches that START there and their device time -- a launch that covers a group
+ * of small levels, or the LDS-resident bottom of the cycle, is booked on its finest level. */
+int mgx_plan_profile_level(const mgx_plan *plan, int level, long *count, double *total_ms);
 const char *mgx_kernel_name(int kernel_id);
 
 /* ------------------------------------------------------------------------
@@ -342,6 +348,10 @@ typedef struct mgx_slab_op {
     int jfix_lo, jfix_hi;   /* local index of Dirichlet columns, or -1          */
     int gf0, gc0;           /* global column index of local column 0            */
     double dx, omega;
+    int jlo2, jhi2;         /* a second range of fine local columns to produce in the same launch,
+                               jlo2 >= jhi (the columns next to both neighbours go out in one
+                               launch ahead of the interior); jlo2 == jhi2: none.  struct_size may
+                               also be offsetof(mgx_slab_op, jlo2): the struct without this pair. */
 } mgx_slab_op;
 int mgx_slab_launch(const mgx_slab_op *op, void *stream);
 
@@ -477,6 +487,10 @@ int mgx_tune_mode(int enable);
  * it to send every candidate shape through a parity check).  Not to be called while another
  * thread launches. */
 int mgx_tune_reset(void);
+/* The shapes measured so far in this process as text, one line per geometry (kernel instance,
+ * device, rows, columns produced, chosen shape); copies at most len-1 characters and a NUL into
+ * buf (which may be NULL) and returns the size the whole text needs, NUL included. */
+size_t mgx_tune_report(char *buf, size_t len);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,7 @@ class mgx_slab_op(ctypes.Structure):
         ("jfix_lo", ctypes.c_int), ("jfix_hi", ctypes.c_int),
         ("gf0", ctypes.c_int), ("gc0", ctypes.c_int),
         ("dx", ctypes.c_double), ("omega", ctypes.c_double),
+        ("jlo2", ctypes.c_int), ("jhi2", ctypes.c_int),
     ]
 
 
@@ -96,6 +97,8 @@ SIGNATURES = {
     "mgx_plan_profile": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mgx_plan_profile_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_long),
                                             ctypes.POINTER(ctypes.c_double)]),
+    "mgx_plan_profile_level": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_long),
+                                              ctypes.POINTER(ctypes.c_double)]),
     "mgx_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
     "mgx_plan_set_dev": (ctypes.c_int, [_vp, _vp, _vp]),
     "mgx_plan_get_dev": (ctypes.c_int, [_vp, _vp]),
@@ -156,6 +159,7 @@ SIGNATURES = {
     "mgx_plan_tune": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     "mgx_tune_mode": (ctypes.c_int, [ctypes.c_int]),
     "mgx_tune_reset": (ctypes.c_int, []),
+    "mgx_tune_report": (ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t]),
     "mgx_plan_set_stream": (ctypes.c_int, [_vp, _vp]),
 }
 
@@ -186,6 +190,15 @@ def check(rc):
         msg = load().mgx_last_error()
         raise MgxError(rc, msg.decode("utf-8", "replace") if msg else "")
     return rc
+
+
+def tune_report():
+    """The launch shapes measured so far in this process (mgx_tune_report), a list of lines."""
+    L = load()
+    n = L.mgx_tune_report(None, 0)
+    buf = ctypes.create_string_buffer(n)
+    L.mgx_tune_report(buf, n)
+    return [l for l in buf.value.decode().splitlines() if l]
 
 
 FLAG_ZERO_GUESS = 1

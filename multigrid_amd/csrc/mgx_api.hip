@@ -103,8 +103,10 @@ struct mgx_plan {
     size_t bytes = 0;
     // per-launch timing of the fine-level kernels (mgx_plan_profile)
     int profile = 0;
-    struct ProfRec { int kid; hipEvent_t a, b; };
+    struct ProfRec { int kid, level; hipEvent_t a, b; };
     std::vector<ProfRec> recs;
+    std::vector<double> lvl_ms;  // profile mode 2: device time of the launches that START at each level
+    std::vector<long> lvl_n;
     std::vector<hipEvent_t> evpool;
     size_t evused = 0;
     double prof_ms[MGX_KERNEL_COUNT] = {0};
@@ -180,13 +182,13 @@ hipEvent_t prof_event(mgx_plan *p)
 // bracket it with two events on the plan's stream.
 #define LAUNCH(p, level, kid, call)                                              \
     do {                                                                         \
-        const bool prof_ = (p)->profile && (level) == 0;                         \
+        const bool prof_ = ((p)->profile && (level) == 0) || (p)->profile == 2;  \
         hipEvent_t ea_ = nullptr, eb_ = nullptr;                                 \
         if (prof_ && (ea_ = prof_event(p))) HIP_TRY(hipEventRecord(ea_, (p)->stream)); \
         HIP_TRY(call);                                                           \
         if (prof_ && ea_ && (eb_ = prof_event(p))) {                             \
             HIP_TRY(hipEventRecord(eb_, (p)->stream));                           \
-            (p)->recs.push_back({(kid), ea_, eb_});                              \
+            (p)->recs.push_back({(kid), (level), ea_, eb_});                     \
         }                                                                        \
     } while (0)
 
@@ -195,8 +197,14 @@ int prof_collect(mgx_plan *p)
     for (const mgx_plan::ProfRec &r : p->recs) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
-        p->prof_ms[r.kid] += (double)ms;
-        p->prof_n[r.kid] += 1;
+        if (r.level == 0 && r.kid >= 0) {
+            p->prof_ms[r.kid] += (double)ms;
+            p->prof_n[r.kid] += 1;
+        }
+        if (p->profile == 2 && r.level >= 0 && r.level < (int)p->lvl_ms.size()) {
+            p->lvl_ms[(size_t)r.level] += (double)ms;
+            p->lvl_n[(size_t)r.level] += 1;
+        }
     }
     p->recs.clear();
     p->evused = 0;
@@ -504,7 +512,11 @@ int fused_tail(mgx_plan *p, int T, const FusedCtx &cx)
     A.nomega = 1 - cx.omega;
     A.exact_tables = p->exact_tables;
     L.cur = 0;
-    HIP_TRY(launch_tail(A, p->stream));
+    if (p->profile == 2) {
+        LAUNCH(p, T, -1, launch_tail(A, p->stream));
+    } else {
+        HIP_TRY(launch_tail(A, p->stream));
+    }
     if (p->verbose && p->lv[p->depth].m != 3 && !p->exact_tables)
         printf("Error: Direct solver not defined for %dx%d matrices!\n", p->lv[p->depth].m, p->lv[p->depth].m);
     return MGX_OK;
@@ -815,8 +827,19 @@ int mgx_plan_commit(mgx_plan *p)
 int mgx_plan_profile(mgx_plan *p, int enable)
 {
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_profile: null plan");
-    p->profile = enable ? 1 : 0;
+    p->profile = enable == 2 ? 2 : (enable ? 1 : 0);
     for (int k = 0; k < MGX_KERNEL_COUNT; k++) { p->prof_ms[k] = 0; p->prof_n[k] = 0; }
+    p->lvl_ms.assign((size_t)p->depth + 1, 0.0);
+    p->lvl_n.assign((size_t)p->depth + 1, 0);
+    return MGX_OK;
+}
+
+int mgx_plan_profile_level(const mgx_plan *p, int level, long *count, double *total_ms)
+{
+    if (!p || level < 0 || level > p->depth) return fail(MGX_ERR_ARG, "mgx_plan_profile_level: bad argument");
+    const bool have = (size_t)level < p->lvl_ms.size();
+    if (count) *count = have ? p->lvl_n[(size_t)level] : 0;
+    if (total_ms) *total_ms = have ? p->lvl_ms[(size_t)level] : 0.0;
     return MGX_OK;
 }
 
@@ -1012,8 +1035,8 @@ int mgx_plan_cycles_until(mgx_plan *p, int max_cycles, int Ndown, int Nup, doubl
     if (max_cycles < 0 || Ndown < 0 || Nup < 0 || batch < 1 || !(rel_tol >= 0.0))
         return fail(MGX_ERR_ARG, "mgx_plan_cycles_until: bad argument");
     std::vector<double> rn((size_t)batch + 1), tm((size_t)batch + 1);
-    int done = 0, why = MGX_STOP_MAX_CYCLES;
-    double r0 = 0, prev = 0, tbase = 0;
+    int done = 0, why = MGX_STOP_MAX_CYCLES, since = 0;
+    double r0 = 0, best = 0, tbase = 0;
     if (times) times[0] = 0;
     while (true) {
         const int n = std::min(batch, max_cycles - done);
@@ -1022,23 +1045,29 @@ int mgx_plan_cycles_until(mgx_plan *p, int max_cycles, int Ndown, int Nup, doubl
         if (rc) return rc;
         if (done == 0) {
             r0 = rn[0];
-            prev = r0;
+            best = r0;
             if (resnorms) resnorms[0] = r0;
         }
         bool stop = false;
         for (int k = 1; k <= n; k++) {
             if (resnorms) resnorms[done + k] = rn[k];
             if (times) times[done + k] = tbase + tm[k];
-            // the first cycle at or below the tolerance, or (after the third cycle) the first that no
-            // longer halves the norm: the residual has reached its rounding floor, eps*8/h^2*max|u|
+            // the first cycle at or below the tolerance, or the third cycle in a row that fails to
+            // bring the norm 10 % below the best seen so far: the residual has reached its
+            // rounding floor, eps*8/h^2*max|u|, where it hovers.  A cycle that merely converges
+            // slowly (a factor of 0.7 with one sweep and a small omega) keeps going.
             if (!stop && rn[k] <= rel_tol * r0) {
                 stop = true;
                 why = MGX_STOP_TOLERANCE;
-            } else if (!stop && done + k > 3 && rn[k] > 0.5 * prev) {
-                stop = true;
-                why = MGX_STOP_FLOOR;
+            } else if (!stop) {
+                if (rn[k] < 0.9 * best) {
+                    best = rn[k];
+                    since = 0;
+                } else if (++since >= 3) {
+                    stop = true;
+                    why = MGX_STOP_FLOOR;
+                }
             }
-            prev = rn[k];
         }
         tbase += tm[n];
         done += n;
@@ -1055,6 +1084,17 @@ int mgx_tune_reset(void)
 {
     tune_forget();
     return MGX_OK;
+}
+
+size_t mgx_tune_report(char *buf, size_t len)
+{
+    const std::string r = tune_report();
+    if (buf && len) {
+        const size_t n = std::min(r.size(), len - 1);
+        memcpy(buf, r.data(), n);
+        buf[n] = 0;
+    }
+    return r.size() + 1;
 }
 
 int mgx_plan_tune(mgx_plan *p, int Ndown, int Nup, double omega)
@@ -1382,8 +1422,10 @@ int mgx_fused_up(const double *coarse_v, double *v, const double *f, int m, doub
 int mgx_slab_launch(const mgx_slab_op *op, void *stream)
 {
     if (!op) return fail(MGX_ERR_ARG, "mgx_slab_launch: null op");
-    if (op->struct_size != (int)sizeof(mgx_slab_op))
-        return fail(MGX_ERR_ARG, "mgx_slab_launch: struct_size %d != %d", op->struct_size, (int)sizeof(mgx_slab_op));
+    // (a caller built against the struct without the second range passes the smaller size)
+    if (op->struct_size != (int)sizeof(mgx_slab_op) && op->struct_size != (int)offsetof(mgx_slab_op, jlo2))
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: struct_size %d is neither %d nor %d", op->struct_size,
+                    (int)sizeof(mgx_slab_op), (int)offsetof(mgx_slab_op, jlo2));
     StreamOp so;
     so.ns = op->nsweeps;
     so.pa = op->pro_stage;
@@ -1404,37 +1446,47 @@ int mgx_slab_launch(const mgx_slab_op *op, void *stream)
     if (!so.store && !so.res && so.nm < 0) return MGX_OK;
     if ((so.pa >= 0 && !op->coarse_v) || (so.res && !op->coarse_f) || (so.nm >= 0 && !op->norm_slot))
         return fail(MGX_ERR_ARG, "mgx_slab_launch: null coarse array or norm slot");
+    // the second produced range exists in the struct from version 210 on
+    const bool has2 = op->struct_size >= (int)sizeof(mgx_slab_op);
+    const int jlo2 = has2 ? op->jlo2 : 0, jhi2 = has2 ? op->jhi2 : 0;
     if (op->jlo < 0 || op->jhi > op->ncols || op->jlo > op->jhi)
         return fail(MGX_ERR_ARG, "mgx_slab_launch: produced range [%d,%d) outside 0..%d", op->jlo, op->jhi, op->ncols);
-    if (op->jlo == op->jhi) return MGX_OK;
+    if (jhi2 < jlo2 || (jhi2 > jlo2 && (jlo2 < op->jhi || jhi2 > op->ncols)))
+        return fail(MGX_ERR_ARG, "mgx_slab_launch: second range [%d,%d) must follow the first [%d,%d) inside 0..%d", jlo2,
+                    jhi2, op->jlo, op->jhi, op->ncols);
+    if (op->jlo == op->jhi && jlo2 == jhi2) return MGX_OK;
     const int flo = op->jfix_lo, fhi = op->jfix_hi;
     if ((flo >= 0 && flo != 0) || (fhi >= 0 && fhi != op->ncols - 1))
         return fail(MGX_ERR_ARG, "mgx_slab_launch: a Dirichlet column must be the first / last column of the slab");
-    if ((flo == 0 && op->jlo < 1) || (fhi >= 0 && op->jhi > fhi))
-        return fail(MGX_ERR_ARG, "mgx_slab_launch: a Dirichlet column cannot be produced");
     // halo the pipeline consumes around the produced columns
     const int need = stream_halo(so);
-    if (flo < 0 && op->jlo - need < 0)
-        return fail(MGX_ERR_ARG, "mgx_slab_launch: %d halo columns needed left of column %d", need, op->jlo);
-    if (fhi < 0 && op->jhi - 1 + need > op->ncols - 1)
-        return fail(MGX_ERR_ARG, "mgx_slab_launch: %d halo columns needed right of column %d", need, op->jhi - 1);
-    if (so.pa >= 0 || so.res) {
-        if (op->mc != (op->m - 1) / 2 + 1 || op->ldc < op->mc || op->nccols < 1)
-            return fail(MGX_ERR_ARG, "mgx_slab_launch: coarse slab %d rows does not pair with %d fine rows", op->mc, op->m);
-        // coarse columns touched: interpolation reads J and J+1 of every column
-        // of stage pro_stage that the produced range depends on; restriction
-        // writes J of the produced even columns
-        int jf_lo = op->jlo, jf_hi = op->jhi - 1;
-        if (so.pa >= 0) {
-            const int reach = need - so.pa;
-            jf_lo = op->jlo - reach < 0 ? 0 : op->jlo - reach;
-            jf_hi = op->jhi - 1 + reach > op->ncols - 1 ? op->ncols - 1 : op->jhi - 1 + reach;
+    for (int rg = 0; rg < 2; rg++) {
+        const int jlo = rg ? jlo2 : op->jlo, jhi = rg ? jhi2 : op->jhi;
+        if (jlo == jhi) continue;
+        if ((flo == 0 && jlo < 1) || (fhi >= 0 && jhi > fhi))
+            return fail(MGX_ERR_ARG, "mgx_slab_launch: a Dirichlet column cannot be produced");
+        if (flo < 0 && jlo - need < 0)
+            return fail(MGX_ERR_ARG, "mgx_slab_launch: %d halo columns needed left of column %d", need, jlo);
+        if (fhi < 0 && jhi - 1 + need > op->ncols - 1)
+            return fail(MGX_ERR_ARG, "mgx_slab_launch: %d halo columns needed right of column %d", need, jhi - 1);
+        if (so.pa >= 0 || so.res) {
+            if (op->mc != (op->m - 1) / 2 + 1 || op->ldc < op->mc || op->nccols < 1)
+                return fail(MGX_ERR_ARG, "mgx_slab_launch: coarse slab %d rows does not pair with %d fine rows", op->mc, op->m);
+            // coarse columns touched: interpolation reads J and J+1 of every column
+            // of stage pro_stage that the produced range depends on; restriction
+            // writes J of the produced even columns
+            int jf_lo = jlo, jf_hi = jhi - 1;
+            if (so.pa >= 0) {
+                const int reach = need - so.pa;
+                jf_lo = jlo - reach < 0 ? 0 : jlo - reach;
+                jf_hi = jhi - 1 + reach > op->ncols - 1 ? op->ncols - 1 : jhi - 1 + reach;
+            }
+            const int Jlo = ((jf_lo + op->gf0) >> 1) - op->gc0;
+            const int Jhi = ((jf_hi + op->gf0 + (so.pa >= 0 ? 1 : 0)) >> 1) - op->gc0;
+            if (Jlo < 0 || Jhi > op->nccols - 1)
+                return fail(MGX_ERR_ARG, "mgx_slab_launch: coarse columns %d..%d outside the coarse slab 0..%d", Jlo, Jhi,
+                            op->nccols - 1);
         }
-        const int Jlo = ((jf_lo + op->gf0) >> 1) - op->gc0;
-        const int Jhi = ((jf_hi + op->gf0 + (so.pa >= 0 ? 1 : 0)) >> 1) - op->gc0;
-        if (Jlo < 0 || Jhi > op->nccols - 1)
-            return fail(MGX_ERR_ARG, "mgx_slab_launch: coarse columns %d..%d outside the coarse slab 0..%d", Jlo, Jhi,
-                        op->nccols - 1);
     }
     if (!(op->dx > 0.0)) return fail(MGX_ERR_ARG, "mgx_slab_launch: dx must be positive");
     StreamArgs A;
@@ -1452,6 +1504,8 @@ int mgx_slab_launch(const mgx_slab_op *op, void *stream)
     A.nccols = op->nccols;
     A.jlo = op->jlo;
     A.jhi = op->jhi;
+    A.jlo2 = jlo2;
+    A.jhi2 = jhi2;
     A.jfix_lo = flo;
     A.jfix_hi = fhi;
     A.gf0 = op->gf0;

@@ -11,6 +11,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace mgx {
 
 // Order-preserving encoding of a norm value for unsigned atomic max:
@@ -165,9 +167,11 @@ struct StreamArgs {
     int mc = 0, ldc = 0;          // coarse rows and pitch
     int nccols = 0;               // coarse local columns that exist
     int jlo = 0, jhi = 0;         // fine local columns to produce: [jlo, jhi)
+    int jlo2 = 0, jhi2 = 0;       // and, if jhi2 > jlo2, a second range [jlo2, jhi2) with jlo2 >= jhi
     int jfix_lo = -1, jfix_hi = -1;  // local index of the physical boundary columns j=0 / j=M-1, or -1
     int gf0 = 0, gc0 = 0;         // global column index of local column 0 (fine, coarse)
     int CJ = 0, nstrips = 0, nchunks = 0, nwv = 4;  // filled by the launcher
+    int nch1 = 0;                 // filled by the launcher: chunks of the first range (the rest march the second)
     int remap = 0;                // filled by the launcher: renumbering of the workgroups over the XCDs (0: none)
     SweepCoef c;
 };
@@ -186,6 +190,8 @@ hipError_t launch_stream(const StreamOp &op, const StreamArgs &A, hipStream_t s)
 bool set_tune_now(bool on);
 // Forget every measured launch shape of this process (the next launches measure again).
 void tune_forget();
+// The shapes measured so far in this process, one text line per geometry.
+std::string tune_report();
 // halo columns (and rows) the pipeline of `op` consumes beyond the produced range
 int stream_halo(const StreamOp &op);
 // The four-flag form of the simple legs: pro in {0,1}; res 0 none, 1 restrict,

@@ -254,6 +254,7 @@ struct OpSpec {
     unsigned long long *norm_slot = nullptr;
     CoarseShape cs;
     int jlo = 0, jhi = 0;
+    int jlo2 = 0, jhi2 = 0;  // a second column range produced by the same launch (none if equal)
     double omega = 0;
 };
 
@@ -283,6 +284,8 @@ int launch(Slab &S, int level, int kid, const OpSpec &o)
     op.nccols = o.cs.nccols;
     op.jlo = o.jlo;
     op.jhi = o.jhi;
+    op.jlo2 = o.jlo2;
+    op.jhi2 = o.jhi2;
     op.jfix_lo = L.jfix_lo;
     op.jfix_hi = L.jfix_hi;
     op.gf0 = L.lo;
@@ -296,7 +299,7 @@ int launch(Slab &S, int level, int kid, const OpSpec &o)
     if (rc != MGX_OK) return slab_fail(S, rc, "slab %d level %d: %s", S.rank, level, mgx_last_error());
     if (prof && a && (b = pool_event(S))) {
         S_HIP(S, hipEventRecord(b, S.compute));
-        S.recs.push_back({kid, a, b, (long)(o.jhi - o.jlo) * L.m});
+        S.recs.push_back({kid, a, b, (long)(o.jhi - o.jlo + o.jhi2 - o.jlo2) * L.m});
     }
     return MGX_OK;
 }
@@ -581,18 +584,20 @@ int launch_level0(Slab &S, int kid, OpSpec o, const std::vector<XItem> &items, b
     bool split = false;
     if (mp->overlap && (lo_nb || hi_nb) && (jhi - jlo) >= 4 * B) {
         split = true;
-        if (lo_nb) {
+        // the columns next to both neighbours go out in ONE launch of two column ranges
+        if (lo_nb) ilo = jlo + B;
+        if (hi_nb) ihi = jhi - B;
+        if (lo_nb && hi_nb) {
             o.jlo = jlo;
-            o.jhi = jlo + B;
-            S_TRY(launch(S, top, -1, o));
-            ilo = jlo + B;
+            o.jhi = ilo;
+            o.jlo2 = ihi;
+            o.jhi2 = jhi;
+        } else {
+            o.jlo = lo_nb ? jlo : ihi;
+            o.jhi = lo_nb ? ilo : jhi;
         }
-        if (hi_nb) {
-            o.jlo = jhi - B;
-            o.jhi = jhi;
-            S_TRY(launch(S, top, -1, o));
-            ihi = jhi - B;
-        }
+        S_TRY(launch(S, top, -1, o));
+        o.jlo2 = o.jhi2 = 0;
     }
     o.jlo = ilo;
     o.jhi = ihi;

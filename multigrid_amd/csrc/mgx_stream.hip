@@ -50,6 +50,7 @@
 #include "mgx_internal.h"
 
 #include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -107,7 +108,9 @@ __device__ __forceinline__ double residual_pt(double uW, double uE, double uS, d
 
 // Neighbour lanes through the wavefront-wide DPP shifts of gfx9 (wave_shr:1 / wave_shl:1, two
 // VALU moves per double) instead of __shfl_up/__shfl_down (two ds_bpermute through the LDS
-// crossbar and a wait each); lanes 0 / 63 keep their own value, like the shuffles.
+// crossbar and a wait each).  Lane 0 / 63, which has no such neighbour, reads 0.0
+// (bound_ctrl; keeping its own value instead would cost a second move per half): that lane's
+// outer row is the outermost halo row of the strip, whose neighbour never reaches an owned point.
 #ifndef MGX_DPP_SHIFT
 #define MGX_DPP_SHIFT 1
 #endif
@@ -115,8 +118,16 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_shift(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
+#ifndef MGX_DPP_BOUND
+#define MGX_DPP_BOUND 1
+#endif
+#if MGX_DPP_BOUND
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+#else
     lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+#endif
     return __hiloint2double(hi, lo);
 }
 #if MGX_DPP_SHIFT
@@ -129,7 +140,10 @@ __device__ __forceinline__ double from_upper_lane(double v) { return __shfl_down
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE, bool EDGE>
+// EDGE: the strip touches row 0 or m-1 (rows are clamped and masked).  CF: the chunk marches
+// over a Dirichlet column or past an end of the array (columns are tested one by one);
+// without it no column of the march is special and the tests fold away.
+template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE, bool EDGE, bool CF>
 __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip, const int chunk)
 {
     using G = Geo<NS, PA, NM, RES>;
@@ -160,14 +174,15 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
     const int rb_c = EDGE ? clampi(rb, 0, m - 1) : rb;
 
     // ---- columns of this chunk -----------------------------------------------
-    const int ja = A.jlo + chunk * A.CJ;
-    const int jb = min(ja + A.CJ, A.jhi);
+    const bool second = chunk >= A.nch1;  // a launch may produce two column ranges
+    const int ja = second ? A.jlo2 + (chunk - A.nch1) * A.CJ : A.jlo + chunk * A.CJ;
+    const int jb = min(ja + A.CJ, second ? A.jhi2 : A.jhi);
     int jstart = ja - G::HLC;
     if (jstart < 0) jstart = 0;
     if ((jstart + A.gf0) & 1) jstart -= 1;  // start the march on an even global column
     const int jlast = jb + G::JLAST;
     const int ncols = A.ncols;
-    const int jfl = A.jfix_lo, jfh = A.jfix_hi;
+    const int jfl = CF ? A.jfix_lo : -1, jfh = CF ? A.jfix_hi : -1;
 
     const double *__restrict__ pua = A.uin + ra_c;
     const double *__restrict__ pub = A.uin + rb_c;
@@ -272,9 +287,11 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
 
     double nacc = 0.0;  // NORM: running max |r| (boundary residuals are +0.0)
 
-    // One column step; ODD is the parity of the global column index of jin.
-    auto step = [&](const int jin, auto odd_tag) {
+    // One column step; ODD is the parity of the global column index of jin, SLOT the place
+    // of column jin in the load-ahead queues (the step number modulo PF).
+    auto step = [&](const int jin, auto odd_tag, auto slot_tag) {
         constexpr bool ODD = decltype(odd_tag)::value;
+        constexpr int SLOT = decltype(slot_tag)::value;
 
         // P(coarse) added to column jp (parity ODDP) of stage PA
         auto add_correction = [&](P2 &x, const int jp, auto oddp_tag) {
@@ -298,7 +315,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
                 s4 = s4 + c1u;
                 pb = 0.25 * s4;
             }
-            const bool colfix = (jp == jfl) || (jp == jfh) || jp < 0 || jp >= ncols;
+            const bool colfix = CF && ((jp == jfl) || (jp == jfh) || jp < 0 || jp >= ncols);
             const double na = x.a + pa;  // main.cpp:341
             const double nb = x.b + pb;
             x.a = (colfix || fixa) ? x.a : na;
@@ -316,22 +333,19 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
             return r;
         };
         auto norm_merge = [&](const P2 &r, const int jr) {
-            const bool colok = jr >= ja && jr < jb && jr != jfl && jr != jfh;
+            const bool colok = jr >= ja && jr < jb && !(CF && (jr == jfl || jr == jfh));
             const double xa = __builtin_fabs(r.a), xb = __builtin_fabs(r.b);
             if (colok && owna) nacc = (nacc < xa) ? xa : nacc;
             if (colok && ownb) nacc = (nacc < xb) ? xb : nacc;
         };
 
-        // ---- take column jin from the load-ahead queue, refill it ----------
-        P2 u0 = Pu[0];
-        const P2 f1 = Pf[0];
-#pragma unroll
-        for (int k = 0; k + 1 < PF; k++) {
-            Pu[k] = Pu[k + 1];
-            Pf[k] = Pf[k + 1];
-        }
-        if (!ZERO_IN) Pu[PF - 1] = load_col(pua, pub, jin + PF);
-        Pf[PF - 1] = load_col(pfa, pfb, jin - 1 + PF, true);
+        // ---- take column jin from its place in the load-ahead queues and refill that place:
+        // a queue that shifted would move registers that loads are still in flight to, and the
+        // moves at the end of a trip would wait for every one of them
+        P2 u0 = Pu[SLOT];
+        const P2 f1 = Pf[SLOT];
+        if (!ZERO_IN) Pu[SLOT] = load_col(pua, pub, jin + PF);
+        Pf[SLOT] = load_col(pfa, pfb, jin - 1 + PF, true);
 
         // ---- stage 0 ---------------------------------------------------------
         if (PA == 0) add_correction(u0, jin, std::integral_constant<bool, ODD>{});
@@ -342,7 +356,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
         for (int k = NS + 1; k > 1; k--) Fq[k] = Fq[k - 1];
         Fq[1] = f1;
         if (NS == 0 && PRO && STORE) {  // prolong + correct only: stage 0 is the output
-            if (jin >= ja && jin < jb && jin != jfl && jin != jfh) store_col(jin, u0);
+            if (jin >= ja && jin < jb && !(CF && (jin == jfl || jin == jfh))) store_col(jin, u0);
         }
         if (NORM && NM == 0 && NS > 0) norm_merge(residual_col(std::integral_constant<int, 0>{}), jin - 1);
 
@@ -351,7 +365,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
             constexpr int s = decltype(s_tag)::value;
             const int jc = jin - s;
             const P2 uS = U[s - 1][0], uC = U[s - 1][1], uN = U[s - 1][2];
-            const bool colfix = (jc == jfl) || (jc == jfh);  // Dirichlet column: untouched by relax
+            const bool colfix = CF && ((jc == jfl) || (jc == jfh));  // Dirichlet column: untouched by relax
             const double wa = from_lower_lane(uC.b);         // row ra-1
             const double eb = from_upper_lane(uC.a);         // row rb+1
             const double na = jacobi_pt(wa, uC.b, uS.a, uN.a, uC.a, Fq[s].a, c);
@@ -386,7 +400,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
                 constexpr bool JR_ODD = ((NS + 1) & 1) ? !ODD : ODD;
                 if (JR_ODD) {
                     const int jcen = jr - 1;
-                    if (jcen >= ja && jcen < jb && jcen != jfl && jcen != jfh) {
+                    if (jcen >= ja && jcen < jb && !(CF && (jcen == jfl || jcen == jfh))) {
                         const double m1 = from_lower_lane(R[1].b);  // row 2I-1, column 2J
                         const double m0 = from_lower_lane(R[0].b);  // row 2I-1, column 2J-1
                         const double t0 = R[1].a * 0.25;            // main.cpp:216-218
@@ -413,21 +427,47 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
         }
     };
 
-    for (int jin = jstart; jin <= jlast; jin += 2) {
 #ifndef MGX_LOCKSTEP
 #define MGX_LOCKSTEP 8
 #endif
-#if MGX_LOCKSTEP > 0
-        // Keep the workgroup's strips within MGX_LOCKSTEP columns of each
-        // other, so that the halo rows two of them share are still in the XCD's
-        // L2 when the second wave reads them (measured on the level-0 launch: none
-        // 1.551 ms, every 64 columns 1.515, 32: 1.500, 16: 1.491, 8: 1.487, 4: 1.487,
-        // 2: 1.497).  All waves of a workgroup march the same chunk, hence the same
-        // trip count; a wave that has exited is not waited for.
-        if (((jin - jstart) & (MGX_LOCKSTEP - 1)) == 0) __builtin_amdgcn_s_barrier();
+#ifndef MGX_UNROLL6
+// Measured on the level-0 launch: the six-column trip executes 20 % fewer vector instructions and
+// is 7 % SLOWER (1.467 -> 1.578 ms): the moves it saves are not what the launch waits for, and its
+// 170 registers and longer trip drain the load queue at a worse moment.  Off.
+#define MGX_UNROLL6 0
 #endif
-        step(jin, std::false_type{});
-        step(jin + 1, std::true_type{});
+    // Keep the workgroup's strips within a few columns of each other, so that the halo rows
+    // two of them share are still in the XCD's L2 when the second wave reads them (measured on
+    // the level-0 launch: no barrier 1.551 ms, every 64 columns 1.515, 32: 1.500, 16: 1.491,
+    // 8: 1.487, 4: 1.487, 2: 1.497).  All waves of a workgroup march the same chunk, hence the
+    // same trip count; a wave that has exited is not waited for.
+    using std::integral_constant;
+    if ((MGX_UNROLL6 && !EDGE) || PF != 2) {
+        // Six columns per trip: the register queues rotate with periods 2 (load-ahead, column
+        // parity), 3 (the three newest columns of a stage, the residual columns, the coarse
+        // columns every other step) and NS+1, so after six steps every value is back in the
+        // register it started in and the rotations cost no moves.  The last trip may march up to
+        // four columns past jlast: loads are clamped, nothing past jb is stored or merged.
+        static_assert(6 % PF == 0, "the load-ahead depth must divide the trip length");
+        for (int jin = jstart; jin <= jlast; jin += 6) {
+#if MGX_LOCKSTEP > 0
+            __builtin_amdgcn_s_barrier();
+#endif
+            step(jin, std::false_type{}, integral_constant<int, 0 % PF>{});
+            step(jin + 1, std::true_type{}, integral_constant<int, 1 % PF>{});
+            step(jin + 2, std::false_type{}, integral_constant<int, 2 % PF>{});
+            step(jin + 3, std::true_type{}, integral_constant<int, 3 % PF>{});
+            step(jin + 4, std::false_type{}, integral_constant<int, 4 % PF>{});
+            step(jin + 5, std::true_type{}, integral_constant<int, 5 % PF>{});
+        }
+    } else {
+        for (int jin = jstart; jin <= jlast; jin += 2) {
+#if MGX_LOCKSTEP > 0
+            if (((jin - jstart) & (MGX_LOCKSTEP - 1)) == 0) __builtin_amdgcn_s_barrier();
+#endif
+            step(jin, std::false_type{}, integral_constant<int, 0>{});
+            step(jin + 1, std::true_type{}, integral_constant<int, 1>{});
+        }
     }
 
     if (NORM) {
@@ -466,10 +506,19 @@ __global__ __launch_bounds__(512) void k_stream(const StreamArgs A)
     if (strip >= A.nstrips) return;
     const int r0 = strip * G::S - G::PADLO;
     const bool edge = (r0 < 1) || (r0 + 127 > A.m - 2);
+    // does the march of this chunk (halo, load-ahead and the columns a six-step trip may add
+    // included) meet a Dirichlet column or leave the array?
+    const bool second = by >= A.nch1;
+    const int ja = second ? A.jlo2 + (by - A.nch1) * A.CJ : A.jlo + by * A.CJ;
+    const int jb = min(ja + A.CJ, second ? A.jhi2 : A.jhi);
+    const int mlo = ja - G::HLC - 2, mhi = jb + G::JLAST + 8;
+    const bool cf = mlo < 0 || mhi >= A.ncols || (A.jfix_lo >= 0 && mlo <= A.jfix_lo) || (A.jfix_hi >= 0 && mhi >= A.jfix_hi);
     if (edge)
-        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, true>(A, strip, by);
+        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, true, true>(A, strip, by);
+    else if (cf)
+        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, false, true>(A, strip, by);
     else
-        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, false>(A, strip, by);
+        stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, false, false>(A, strip, by);
 }
 
 int env_int(const char *name, int dflt)
@@ -591,12 +640,12 @@ bool capped_shape(int nstrips, int ncolsout, LaunchShape &sh, bool longer = fals
 // per geometry and process; after that nothing blocks.  MGX_TUNE=0 turns this off
 // (square-ish launches of at least 12000 columns then take the cap, others the plain shape).
 struct ShapeTuner {
-    static constexpr int MAXC = 4, WINDOW = 3;
+    static constexpr int MAXC = 8, WINDOW = 3;
     struct Entry {
-        int device = -1, m = 0, ncols = 0;
+        int device = -1, m = 0, ncols = 0, nranges = 1;
         int ncand = 0;
         LaunchShape cand[MAXC];
-        float time[MAXC] = {0, 0, 0, 0};
+        float time[MAXC] = {0};
         int chosen = -1, cur = 0, count = -1;  // count -1: one untimed launch first (cold start)
         hipEvent_t e0[WINDOW] = {nullptr}, e1[WINDOW] = {nullptr};
     };
@@ -627,17 +676,19 @@ struct ShapeTuner {
             }
         entries.clear();
     }
-    Entry &find(int device, int m, int ncols)
+    Entry &find(int device, int m, int ncols, int nranges)
     {
         for (Entry &e : entries)
-            if (e.device == device && e.m == m && e.ncols == ncols) return e;
+            if (e.device == device && e.m == m && e.ncols == ncols && e.nranges == nranges) return e;
         entries.emplace_back();
         Entry &e = entries.back();
         e.device = device;
         e.m = m;
         e.ncols = ncols;
+        e.nranges = nranges;
         return e;
     }
+    int sig[6] = {0, 0, 0, 0, 0, 0};  // NS, PA, NM, RES, ZERO_IN, STORE of the kernel instance this tuner serves
 };
 
 thread_local bool g_tune_now = false;
@@ -659,17 +710,36 @@ void report_choice(const ShapeTuner::Entry &e, int m, int ncolsout)
 bool same_shape(const LaunchShape &a, const LaunchShape &b) { return a.nwv == b.nwv && a.CJ == b.CJ && a.lds == b.lds; }
 
 template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
-hipError_t launch_shape(StreamArgs A, const LaunchShape &sh, int ncolsout, hipStream_t s)
+hipError_t launch_shape(StreamArgs A, const LaunchShape &sh, hipStream_t s)
 {
     static const int remap = env_int("MGX_XCD_REMAP", 1);
     A.CJ = sh.CJ;
     A.nwv = sh.nwv;
     A.remap = remap;
-    A.nchunks = (ncolsout + sh.CJ - 1) / sh.CJ;
+    A.nch1 = (A.jhi - A.jlo + sh.CJ - 1) / sh.CJ;
+    A.nchunks = A.nch1 + (A.jhi2 > A.jlo2 ? (A.jhi2 - A.jlo2 + sh.CJ - 1) / sh.CJ : 0);
     const int nsg = (A.nstrips + sh.nwv - 1) / sh.nwv;
     hipLaunchKernelGGL((k_stream<NS, PA, NM, RES, ZERO_IN, STORE>), dim3((unsigned)nsg, (unsigned)A.nchunks),
                        dim3(64 * (unsigned)sh.nwv), sh.lds, s, A);
     return hipGetLastError();
+}
+
+// One workgroup slot per CU filled exactly once: `per_cu` workgroups of `nwv` strips on every CU,
+// all resident from the start, chunks as long as that allows.  For a tall slab of a partitioned
+// level (16385 rows x 2048 columns: 18 groups of eight strips x 14 chunks of 146 columns) the
+// shapes above leave chunks of 64-90 columns, of which the 11 halo columns are a sixth.
+bool one_round_shape(int nstrips, int ncolsout, int nwv, int per_cu, LaunchShape &sh)
+{
+    const long nsg = (nstrips + nwv - 1) / nwv;
+    const long nch = (long)per_cu * cu_count() / nsg;
+    if (nch < 1) return false;
+    int cj = (int)((ncolsout + nch - 1) / nch);
+    cj += cj & 1;
+    if (cj < 48) return false;
+    sh.nwv = nwv;
+    sh.CJ = cj;
+    sh.lds = 0;
+    return true;
 }
 
 template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
@@ -678,38 +748,67 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
     using G = Geo<NS, PA, NM, RES>;
     const int m = A.m;
     A.nstrips = (m - 1 + G::S - 1) / G::S;  // strips own rows 0..m-2
-    const int ncolsout = A.jhi - A.jlo;
+    const int nranges = A.jhi2 > A.jlo2 ? 2 : 1;
+    const int ncolsout = (A.jhi - A.jlo) + (nranges == 2 ? A.jhi2 - A.jlo2 : 0);
     if (ncolsout <= 0 || m < 3) return hipSuccess;
+    if (A.jhi <= A.jlo) {  // only the second range holds columns
+        A.jlo = A.jlo2;
+        A.jhi = A.jhi2;
+        A.jlo2 = A.jhi2 = 0;
+    }
     const LaunchShape plain = plain_shape(A.nstrips, ncolsout);
     // candidates: the static guess first (it is the fallback), then the others
     LaunchShape cands[ShapeTuner::MAXC];
     int ncands = 0;
-    cands[ncands++] = plain;
+    auto add = [&](const LaunchShape &c) {
+        for (int k = 0; k < ncands; k++)
+            if (same_shape(cands[k], c)) return;
+        if (ncands < ShapeTuner::MAXC) cands[ncands++] = c;
+    };
+    add(plain);
     if (!ZERO_IN && (long)m * ncolsout >= (8L << 20)) {
         LaunchShape capped = plain;
         if (capped_shape(A.nstrips, ncolsout, capped)) {
-            cands[ncands++] = capped;
-            if (4L * ncolsout >= 3L * m && ncolsout >= 12000) std::swap(cands[0], cands[1]);  // a big square level
+            add(capped);
+            if (ncands == 2 && 4L * ncolsout >= 3L * m && ncolsout >= 12000) std::swap(cands[0], cands[1]);  // a big square level
             LaunchShape longer = plain;
-            if (capped_shape(A.nstrips, ncolsout, longer, true) && !same_shape(longer, capped)) cands[ncands++] = longer;
+            if (capped_shape(A.nstrips, ncolsout, longer, true)) add(longer);
         }
-        const LaunchShape wide = plain_shape(A.nstrips, ncolsout, 3, 60);
-        if (!same_shape(wide, plain)) cands[ncands++] = wide;
+        add(plain_shape(A.nstrips, ncolsout, 3, 60));
+        if (4L * ncolsout < 3L * m) {  // a tall slab
+            LaunchShape r = plain;
+            if (one_round_shape(A.nstrips, ncolsout, 8, 1, r)) add(r);
+            if (one_round_shape(A.nstrips, ncolsout, 4, 2, r)) add(r);
+        }
+    } else if (!ZERO_IN && A.nstrips >= 32 && (long)m * ncolsout >= (1L << 20)) {
+        // A narrow band of a tall level (the columns next to a neighbour, launched ahead of the
+        // rest so that the exchange can start): the plain rule would cut it into chunks of 4
+        // columns, each marching its 11 halo columns too.  Longer chunks move fewer bytes, fewer
+        // chunks march longer: measured.
+        const int width = std::max(A.jhi - A.jlo, A.jhi2 - A.jlo2);
+        for (int div : {2, 4, 6, 8, 12}) {
+            LaunchShape c = plain;
+            c.nwv = 4;
+            c.CJ = (width + div - 1) / div;
+            c.CJ += c.CJ & 1;
+            if (c.CJ >= 6) add(c);
+        }
     }
     static const int tune = env_int("MGX_TUNE", 1);
-    if (ncands == 1 || !tune) return launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, cands[0], ncolsout, s);
+    if (ncands == 1 || !tune) return launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, cands[0], s);
 
     static ShapeTuner tuner;  // one per kernel instance
+    tuner.sig[0] = NS, tuner.sig[1] = PA, tuner.sig[2] = NM, tuner.sig[3] = RES, tuner.sig[4] = ZERO_IN, tuner.sig[5] = STORE;
     std::lock_guard<std::mutex> lock(tuner.mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    ShapeTuner::Entry &e = tuner.find(dev, m, ncolsout);
+    ShapeTuner::Entry &e = tuner.find(dev, m, ncolsout, nranges);
     if (e.ncand == 0) {
         for (int k = 0; k < ncands; k++) e.cand[e.ncand++] = cands[k];
         for (int w = 0; w < ShapeTuner::WINDOW; w++)
             if (hipEventCreate(&e.e0[w]) != hipSuccess || hipEventCreate(&e.e1[w]) != hipSuccess) e.chosen = 0;
     }
-    if (e.chosen >= 0) return launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[e.chosen], ncolsout, s);
+    if (e.chosen >= 0) return launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[e.chosen], s);
     if (tune_now_flag()) {
         // Decide at once: a launch reads uin/f/cin and writes uout/cout (never its own input)
         // and merges the norm by a max, so repeating it leaves the same result.  Every
@@ -721,10 +820,10 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
         // decide between shapes that differ by 2 %
         for (int pass = 0; pass < 2 && ok; pass++)
             for (int k = 0; k < e.ncand && ok; k++) {
-                rc = launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[k], ncolsout, s);
+                rc = launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[k], s);
                 ok = rc == hipSuccess && hipEventRecord(e.e0[0], s) == hipSuccess;
                 for (int w = 0; ok && w < ShapeTuner::WINDOW; w++) {
-                    rc = launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[k], ncolsout, s);
+                    rc = launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[k], s);
                     ok = rc == hipSuccess;
                 }
                 float t = 0.f;
@@ -735,7 +834,7 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
         if (!ok) {
             if (rc == hipSuccess) (void)hipGetLastError();
             e.chosen = 0;
-            return rc != hipSuccess ? rc : launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[0], ncolsout, s);
+            return rc != hipSuccess ? rc : launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[0], s);
         }
         e.chosen = 0;
         for (int k = 1; k < e.ncand; k++)
@@ -745,12 +844,12 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
     }
     if (e.count < 0) {
         e.count = 0;
-        return launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[0], ncolsout, s);
+        return launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[0], s);
     }
     // (an event record fails e.g. on a stream under capture: tuning is then given up)
     bool ok = hipEventRecord(e.e0[e.count], s) == hipSuccess;
-    const hipError_t rc = ok ? launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[e.cur], ncolsout, s)
-                             : launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[0], ncolsout, s);
+    const hipError_t rc = ok ? launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[e.cur], s)
+                             : launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[0], s);
     ok = ok && rc == hipSuccess && hipEventRecord(e.e1[e.count], s) == hipSuccess;
     if (ok && ++e.count == ShapeTuner::WINDOW) {
         float ms = 0.f;
@@ -779,6 +878,26 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
 }
 
 } // namespace
+
+// One line per measured geometry: kernel instance, rows, columns produced, chosen shape.
+std::string tune_report()
+{
+    std::string out;
+    char buf[256];
+    std::lock_guard<std::mutex> lock(ShapeTuner::registry_mutex());
+    for (ShapeTuner *t : ShapeTuner::registry()) {
+        std::lock_guard<std::mutex> lk(t->mu);
+        for (const ShapeTuner::Entry &e : t->entries) {
+            if (e.chosen < 0) continue;
+            const LaunchShape &c = e.cand[e.chosen];
+            snprintf(buf, sizeof(buf), "k_stream<%d,%d,%d,%d,%d,%d> dev %d m=%d cols=%d%s: %d strips x %d cols%s (%d of %d)\n",
+                     t->sig[0], t->sig[1], t->sig[2], t->sig[3], t->sig[4], t->sig[5], e.device, e.m, e.ncols,
+                     e.nranges == 2 ? " (2 ranges)" : "", c.nwv, c.CJ, c.lds ? ", capped" : "", e.chosen + 1, e.ncand);
+            out += buf;
+        }
+    }
+    return out;
+}
 
 void tune_forget()
 {

@@ -45,7 +45,7 @@ class SlabOp:
     """Arguments of one fused slab launch (mirrors mgx_slab_op in include/mgx.h)."""
     __slots__ = ("nsweeps", "pro_stage", "norm_stage", "restrict_out", "zero_in", "store", "v_in", "v_out", "f",
                  "coarse_v", "coarse_f", "norm_slot", "m", "ncols", "mc", "nccols", "jlo", "jhi", "jfix_lo", "jfix_hi",
-                 "gf0", "gc0", "dx", "omega")
+                 "gf0", "gc0", "dx", "omega", "jlo2", "jhi2")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -106,6 +106,7 @@ class HipBackend:
         o.m, o.ld, o.ncols = op.m, op.m, op.ncols
         o.mc, o.ldc, o.nccols = op.mc or 0, op.mc or 0, op.nccols or 0
         o.jlo, o.jhi, o.jfix_lo, o.jfix_hi = op.jlo, op.jhi, op.jfix_lo, op.jfix_hi
+        o.jlo2, o.jhi2 = op.jlo2 or 0, op.jhi2 or 0
         o.gf0, o.gc0 = op.gf0, op.gc0 or 0
         o.dx, o.omega = op.dx, op.omega
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -534,7 +535,7 @@ class SlabSolver:
             self.be.launch(op)
             b.record()
             self._prof_recs.append((name, a, b))
-            self._prof_pts[name] = self._prof_pts.get(name, 0) + (op.jhi - op.jlo) * op.m
+            self._prof_pts[name] = self._prof_pts.get(name, 0) + (op.jhi - op.jlo + (op.jhi2 or 0) - (op.jlo2 or 0)) * op.m
         else:
             self.be.launch(op)
 
@@ -559,10 +560,15 @@ class SlabSolver:
             if hi_nb:
                 edges.append((jhi - B, jhi))
                 ihi = jhi - B
-        ops = [make_op(r) for r in edges]
+        # the columns next to both neighbours go out in ONE launch of two column ranges
+        edge_op = None
+        if edges:
+            edge_op = make_op(edges[0])
+            if len(edges) == 2:
+                edge_op.jlo2, edge_op.jhi2 = edges[1]
         interior = make_op((ilo, ihi))  # built before the flip: it names the buffers explicitly
-        for op in ops:
-            self._launch(0, "k_stream:edge", op)
+        if edge_op is not None:
+            self._launch(0, "k_stream:edge", edge_op)
         if flip:
             L0.cur ^= 1                 # from here on v[cur] is the buffer being written
         if edges:

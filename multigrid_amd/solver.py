@@ -273,8 +273,21 @@ class Plan:
         _lib.check(self._L.mgx_plan_tune(self._h, Ndown, Nup, omega))
 
     def profile(self, enable=True):
-        """Start (and reset) or stop per-launch timing of the fine-level kernels."""
-        _lib.check(self._L.mgx_plan_profile(self._h, int(bool(enable))))
+        """Start (and reset) or stop per-launch timing of the fine-level kernels; enable=2
+        brackets the launches of every level (see profile_levels)."""
+        _lib.check(self._L.mgx_plan_profile(self._h, 2 if enable == 2 else int(bool(enable))))
+
+    def profile_levels(self):
+        """After profile(2): [(level, rows, launches, total ms)] for the levels that start a
+        launch; a launch over a group of small levels is booked on its finest level."""
+        out = []
+        for d in range(self.depth + 1):
+            n = ctypes.c_long(0)
+            ms = ctypes.c_double(0.0)
+            _lib.check(self._L.mgx_plan_profile_level(self._h, d, ctypes.byref(n), ctypes.byref(ms)))
+            if n.value:
+                out.append((d, self.level_m(d), n.value, ms.value))
+        return out
 
     def profile_totals(self):
         """{kernel name: (launch count, total milliseconds)} since profile(True)."""

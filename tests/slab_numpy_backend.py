@@ -117,6 +117,10 @@ class NumpyBackend:
         invh2 = 1.0 / h2
         omega, nomega = op.omega, 1 - op.omega
         fixed = [j for j in (op.jfix_lo, op.jfix_hi) if j is not None and j >= 0]
+        # the produced columns: one range, or two (the columns next to both neighbours in one launch)
+        ranges = [(op.jlo, op.jhi)]
+        if getattr(op, "jhi2", None) and op.jhi2 > op.jlo2:
+            ranges.append((op.jlo2, op.jhi2))
         u = np.zeros((ncols, m)) if op.zero_in else np.array(op.v_in, copy=True)
         for s in range(op.nsweeps + 1):
             if s > 0:
@@ -136,15 +140,17 @@ class NumpyBackend:
                 r = np.zeros((ncols, m))
                 r[1:-1, 1:-1] = _residual(u, op.f, invh2)
                 slots, k = op.norm_slot
-                val = float(np.max(np.abs(r[op.jlo:op.jhi, 1:m - 1]))) if op.jhi > op.jlo else 0.0
-                slots[k] = max(int(slots[k]), _encode(max(val, 0.0)))
+                for a, b in ranges:
+                    val = float(np.max(np.abs(r[a:b, 1:m - 1]))) if b > a else 0.0
+                    slots[k] = max(int(slots[k]), _encode(max(val, 0.0)))
         if op.store:
-            op.v_out[op.jlo:op.jhi, 1:m - 1] = u[op.jlo:op.jhi, 1:m - 1]
+            for a, b in ranges:
+                op.v_out[a:b, 1:m - 1] = u[a:b, 1:m - 1]
         if op.restrict_out:
             r = np.zeros((ncols, m))
             r[1:-1, 1:-1] = _residual(u, op.f, invh2)
             cf = op.coarse_f
-            for j in range(op.jlo, op.jhi):
+            for j in [j for a, b in ranges for j in range(a, b)]:
                 jg = j + op.gf0
                 if jg & 1:
                     continue

@@ -28,7 +28,7 @@ def test_exports_every_declared_symbol():
 
 def test_version_and_options_layout():
     L = _lib().load()
-    assert L.mgx_version() == 200
+    assert L.mgx_version() == 210
     assert ctypes.sizeof(_lib().mgx_options) == 4 + 4 + 8 + 4 + 4 + 32
 
 
