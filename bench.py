@@ -65,8 +65,26 @@ def fused_bytes_per_point(kernel, nd, nu):
 # HBM bytes per launch from the PMC counters (rocprofv3 --pmc, separate passes, gfx950
 # corrections applied) for the default workload, measured in a SEPARATE profiled run of
 # this same command and kept with the round's profiles.  Reported as `traffic_profiled`
-# (never as `traffic`, which is reserved for something this run measured itself).
-PMC_TRAFFIC = {("k_stream:updown", 16385, 2, 2): (7.784e9, "profiles/r02_final_pmc_traffic.txt")}
+# (never as `traffic`, which is reserved for something this run measured itself).  The figure
+# is read from the profile summary itself, so the two cannot drift apart.
+PMC_TRAFFIC_FILES = ["profiles/r03_final_pmc_traffic.txt"]
+
+
+def profiled_traffic(kernel_rocprof_name):
+    """(bytes per launch, file) of the dominant launch from the newest committed PMC summary
+    (profiles/pmc_summary.py output of `bench.py` with its default workload): the line of this
+    kernel that is marked as the launch shape the timed region used; (None, None) if there is none."""
+    import re
+    short = kernel_rocprof_name.replace("mgx::(anonymous namespace)::", "")
+    for rel in PMC_TRAFFIC_FILES:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        for ln in open(path):
+            m = re.search(r"corrected=([0-9.]+) GB", ln)
+            if m and ln.startswith(short) and "timed-region shape" in ln:
+                return float(m.group(1)) * 1e9, rel
+    return None, None
 
 
 def rocprof_kernel_name(kernel, nd, nu):
@@ -130,22 +148,47 @@ def cpu_baseline(M, nd, nu, omega, omp=False, coarsest=2, exact=False):
 
 def cpu_baseline_reference(M, nd, nu, omega, coarsest=2):
     """The reference's OWN MultiGrid() (main.cpp:283-357 compiled from the reference checkout
-    into oracle/_ref/librefops.so where that checkout exists; the built library travels with
-    the tree) timed on one core: one V-cycle at M x M.  None if the library was not built."""
+    where that checkout exists; the built libraries travel with the tree) timed on one core,
+    one V-cycle at M x M, in two builds: oracle/_ref/librefops_release.so with the flags the
+    reference's Release configuration ships (-O3 -Ofast -DNDEBUG, CMakeLists.txt:17) -- the stated
+    baseline -- and oracle/_ref/librefops.so (-O2, no fast-math), the build the parity tests pin
+    the oracle with.  None if neither library was built."""
     import numpy as np
     from oracle import oracle as O
     from multigrid_amd import rhs
-    if O.ref_ops() is None:
-        return None
-    R = O.Ref()
-    f = rhs.random_np(M)
-    v = np.zeros((M, M), order="F")
-    t0 = time.perf_counter()
-    _, _, tim = R.multigrid(f, v, 1.0 / (M - 1), 1, nd, nu, omega, coarsest)
-    dt = time.perf_counter() - t0
-    return {"value": M * M / dt, "unit": "DOF/s", "cores": 1, "kind": "reference",
-            "sample": "1 V(%d,%d) cycle at %dx%d by the reference's MultiGrid() itself (-O2, its Release build uses "
-                      "-Ofast), %.1f s of which %.1f s inside relax() by its own Times" % (nd, nu, M, M, dt, float(tim[-1]))}
+    # the reference allocates ~7 arrays of the fine size on top of f and v: stay within the host
+    avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    while M > 1025 and 10.0 * 8.0 * M * M > 0.5 * avail:
+        M = (M - 1) // 2 + 1
+    out = None
+    for release in (True, False):
+        if (O.ref_ops_release() if release else O.ref_ops()) is None:
+            continue
+        R = O.Ref(release=release)
+        f = rhs.random_np(M)
+        v = np.zeros((M, M), order="F")
+        t0 = time.perf_counter()
+        _, _, tim = R.multigrid(f, v, 1.0 / (M - 1), 1, nd, nu, omega, coarsest)
+        dt = time.perf_counter() - t0
+        rec = {"value": M * M / dt, "unit": "DOF/s", "cores": 1, "kind": "reference",
+               "build": "-O3 -Ofast -DNDEBUG (the reference's Release flags)" if release else "-O2, no fast-math (the parity build)",
+               "sample": "1 V(%d,%d) cycle at %dx%d by the reference's MultiGrid() itself, %.1f s of which %.1f s inside "
+                         "relax() by its own Times" % (nd, nu, M, M, dt, float(tim[-1]))}
+        if out is None:
+            out = rec
+        else:
+            out["parity_build"] = rec
+    return out
+
+
+def comm_counters(solver):
+    """(neighbour exchanges, tail gathers) a solver has begun so far."""
+    if hasattr(solver, "comm"):
+        return solver.comm.nexchanges, solver.comm.ngathers
+    if hasattr(solver, "stats"):
+        st = solver.stats()
+        return st[0], st[1]
+    return 0, 0
 
 
 def launch_ranks(n, out_fd):
@@ -318,6 +361,7 @@ def main():
     if W > 0:
         solver.cycles(W, args.nd, args.nu, args.omega)
     solver.profile(True)
+    comm_before = comm_counters(solver)
     barrier()
     t0 = time.perf_counter()
     out = solver.cycles(K, args.nd, args.nu, args.omega)
@@ -329,6 +373,37 @@ def main():
         elapsed = float(t.item())
     prof = solver.profile_totals()
     solver.profile(False)
+
+    # what each rank ran: its level-0 launch times, the launch shapes its tuner chose, the
+    # exchanges and gathers it began in the timed region
+    from multigrid_amd import _lib as mglib
+    comm_now = comm_counters(solver)
+    info = {"rank": rank, "device": dev,
+            "level0_avg_ms": {k: round(ms / c, 5) for k, (c, ms) in prof.items() if c},
+            "exchanges_per_cycle": (comm_now[0] - comm_before[0]) / float(K),
+            "gathers_per_cycle": (comm_now[1] - comm_before[1]) / float(K),
+            "launch_shapes": mglib.tune_report()}
+    infos = [info]
+    if grouped:
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
+
+    # where the cycle's time goes, level by level (single plan): a few more cycles with every
+    # launch bracketed by events, outside the timed region
+    levels = None
+    if world == 1 and not args.slab and args.mplan == 0 and args.schedule != 1 and hasattr(solver, "profile_levels"):
+        nlev = 5
+        solver.profile(2)
+        solver.cycles(nlev, args.nd, args.nu, args.omega)
+        rows = solver.profile_levels()
+        solver.profile(False)
+        levels = []
+        for (d, m_d, n, ms) in rows:
+            comp = 28.0 * float(m_d) * m_d if d < 4 else None
+            us = ms * 1e3 / nlev
+            levels.append({"level": d, "m": m_d, "launches_per_cycle": n / float(nlev), "us_per_cycle": round(us, 2),
+                           "compulsory_bytes": comp,
+                           "frac": round(comp / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if comp else None})
 
     if rank == 0:
         n0 = float(M) * M
@@ -353,7 +428,8 @@ def main():
             fbpp = fused_bytes_per_point(kname, args.nd, args.nu) or bpp
             achieved = fbpp * pts / avg_s / 1e9
             whole_grid = world == 1 and not args.slab and args.mplan == 0  # the profiled launch is the single-plan one
-            prof_traffic, prof_src = PMC_TRAFFIC.get((kname, M, args.nd, args.nu), (None, None)) if whole_grid else (None, None)
+            prof_traffic, prof_src = (profiled_traffic(rocprof_kernel_name(kname, args.nd, args.nu))
+                                      if whole_grid and (M, args.nd, args.nu) == (16385, 2, 2) else (None, None))
             roof = {"bound": "hbm", "kernel": rocprof_kernel_name(kname, args.nd, args.nu),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None,
@@ -384,6 +460,21 @@ def main():
             "resnorm_first_last": [float(out.ResidualNorms[0]), float(out.ResidualNorms[-1])],
             "roofline": roof,
         }
+        if levels:
+            line["levels"] = levels
+            line["levels_note"] = ("a separate run of 5 cycles with every launch between events (adds a few us per "
+                                   "small launch); a launch over several small levels is booked on its finest level; "
+                                   "the level-0 figure includes the opening down and closing up launch of the call")
+        if grouped or args.slab or args.mplan:
+            main = [i["level0_avg_ms"].get(kname) for i in infos if i and i["level0_avg_ms"].get(kname)] if roof else []
+            line["comm"] = {
+                "backend": dist.get_backend() if grouped else ("peer copies in one process" if args.mplan else "none"),
+                "rccl_world": dist.get_world_size() if grouped else 1,
+                "launcher": os.environ.get("MGX_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
+                                           else "environment"),
+                "exchanges_per_cycle": infos[0]["exchanges_per_cycle"], "gathers_per_cycle": infos[0]["gathers_per_cycle"],
+                "level0_launch_ms_min_max_over_ranks": [min(main), max(main)] if main else None,
+                "per_rank": infos}
         if world == 1 and args.cpu_baseline == "auto":
             try:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega, False,
@@ -391,8 +482,7 @@ def main():
                 line["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_size or M, args.nd, args.nu, args.omega, True,
                                                               args.coarsest, args.exact_coarse)
                 if not args.exact_coarse:
-                    ref = cpu_baseline_reference(min(args.cpu_size or M, 8193), args.nd, args.nu, args.omega,
-                                                 args.coarsest)
+                    ref = cpu_baseline_reference(args.cpu_size or M, args.nd, args.nu, args.omega, args.coarsest)
                     if ref:
                         line["cpu_baseline_reference"] = ref
             except Exception as e:  # the oracle is a checker; its absence must not hide the GPU number

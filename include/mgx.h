@@ -138,10 +138,11 @@ int mgx_plan_level_m(const mgx_plan *plan, int level);
 size_t mgx_plan_bytes(const mgx_plan *plan); /* HBM held by the plan */
 
 /* Fine-level device buffers (m*m doubles each) the caller may fill directly,
- * e.g. from a kernel of its own.  After writing v through this pointer call
- * mgx_plan_commit() so the plan refreshes its second (ping-pong) copy of the
- * boundary values.  mgx_plan_v_dev() names the buffer that holds the current
- * iterate: the two ping-pong buffers may trade places inside mgx_plan_cycles()
+ * e.g. from a kernel of its own.  After writing f or v through these pointers call
+ * mgx_plan_commit(): the plan refreshes its other copies of the boundary values
+ * and forgets what it may have computed ahead from the old data (see
+ * mgx_plan_cycles).  mgx_plan_v_dev() names the buffer that holds the current
+ * iterate: the plan's iterate buffers trade places inside mgx_plan_cycles()
  * (no copy of the grid), so ask again after it returns.  mgx_plan_f_dev() never
  * changes, and mgx_plan_vcycle_async() leaves mgx_plan_v_dev() as it is. */
 double *mgx_plan_f_dev(mgx_plan *plan);
@@ -168,7 +169,14 @@ int mgx_plan_download(mgx_plan *plan, double *v_host);
  * Coarse-level v is zero again after every cycle (main.cpp:345), so repeated calls
  * continue from the current fine v exactly as one longer call would.  The
  * per-cycle residual norm is always computed on the device, as the reference
- * does; NULL only skips the copy to the host. */
+ * does; NULL only skips the copy to the host.
+ * A caller that stops on a tolerance runs one cycle (or a few) per call.  Such calls cost
+ * what one long call costs: once two calls in a row have continued their predecessor (same
+ * Ndown >= 1, Nup, omega with Ndown + Nup <= 4, no mgx_plan_commit / set / upload in
+ * between), a call's last launch also runs the next call's opening sweeps and restriction
+ * (it writes the end-of-cycle iterate, which the caller sees, and the swept one side by side),
+ * and the next such call starts from there: one level-0 launch per cycle instead of two.
+ * Same bits either way.  A single long call never pays the extra store. */
 int mgx_plan_cycles(mgx_plan *plan, int Nv, int Ndown, int Nup, double omega, int pure_jacobi,
                     double *resnorms, double *times);
 

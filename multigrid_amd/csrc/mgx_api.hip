@@ -115,6 +115,25 @@ struct mgx_plan {
     struct RelaxRec { int cycle; hipEvent_t a, b; };
     std::vector<RelaxRec> relax_recs;
     int relax_cycle = -1;  // >= 0 while mgx_plan_cycles() wants relax() bracketed
+    // Carry between calls (fused lean schedule, Ndown >= 1).  A caller that runs one cycle per
+    // call would pay two level-0 launches per cycle: an opening down leg and a closing up leg,
+    // which a longer call fuses into one launch per cycle.  So a call may end with the fused
+    // up+down launch too, which leaves the iterate after the NEXT cycle's down sweeps and that
+    // cycle's coarse right-hand side; the next call with the same Ndown, Nup and omega, and no
+    // change of the data in between, starts from there.  The end-of-cycle iterate itself (what
+    // mgx_plan_v_dev() names) is then not in memory: it is `lazy`, and materialize() produces
+    // it when somebody asks -- one plain up leg from the closing launch's input, which is kept,
+    // into the array `r` that the fused schedule does not use otherwise.  A call ends this way
+    // when the two calls before it were such continuations (or inside mgx_plan_cycles_until):
+    // a single long call never pays for it.
+    bool carry_capable = true;  // false for the views full multigrid cycles on
+    bool lazy = false;          // v[0] = swept iterate, v[1] = the closing launch's input, result not computed
+    bool carry_valid = false;   // (not lazy) v[0] = result, r = swept iterate; lv[1].f its restricted residual
+    bool force_carry = false;
+    bool last_valid = false;    // the previous call's parameters are below and the data is as it left it
+    int last_Ndown = 0, last_Nup = 0, streak = 0;
+    double last_omega = 0;
+    unsigned long long carry_key = 0;  // encoded norm after the previous call's last cycle
 };
 
 namespace {
@@ -262,7 +281,62 @@ int normalize_boundary(mgx_plan *p)
     Level &L = p->lv[0];
     HIP_TRY(launch_boundary_plus_zero(L.v[0], L.m, p->stream));
     HIP_TRY(launch_boundary_plus_zero(L.v[1], L.m, p->stream));
+    // the third array a call's closing launch may write the iterate to (see `carry_valid`)
+    if (p->carry_capable && p->schedule == MGX_SCHEDULE_FUSED) HIP_TRY(launch_boundary_plus_zero(p->r, L.m, p->stream));
     return MGX_OK;
+}
+
+// the four boundary lines of an m x m array from another (columns 0 and m-1 are contiguous,
+// rows 0 and m-1 one double per column)
+int copy_boundary(double *dst, const double *src, int m, hipStream_t s)
+{
+    const size_t col = sizeof(double) * (size_t)m;
+    HIP_TRY(hipMemcpyAsync(dst, src, col, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dst + (size_t)(m - 1) * m, src + (size_t)(m - 1) * m, col, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpy2DAsync(dst, col, src, col, sizeof(double), (size_t)m, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpy2DAsync(dst + (m - 1), col, src + (m - 1), col, sizeof(double), (size_t)m, hipMemcpyDeviceToDevice, s));
+    return MGX_OK;
+}
+
+struct Level;
+StreamArgs level_args(const Level &L, const Level *C, double omega);
+
+// The end-of-cycle iterate of a call that ended with the fused up+down launch: the plain up leg
+// (refine + add + Nup sweeps, main.cpp:337-344) from that launch's input and the level-1
+// correction, both still in place, into `r`; afterwards v[0] names it and `r` the swept iterate.
+int materialize(mgx_plan *p)
+{
+    if (!p->lazy) return MGX_OK;
+    Level &L = p->lv[0];
+    Level &C = p->lv[1];
+    StreamArgs A = level_args(L, &C, p->last_omega);
+    A.cin = C.v[C.cur];
+    A.uin = L.v[1];
+    A.uout = p->r;
+    StreamOp op;
+    op.ns = p->last_Nup;
+    op.pa = 0;
+    HIP_TRY(launch_stream(op, A, p->stream));
+    double *result = p->r;
+    p->r = L.v[0];
+    L.v[0] = result;
+    L.cur = 0;
+    p->lazy = false;
+    p->carry_valid = true;
+    return MGX_OK;
+}
+
+// The data is about to change (or to be used in another way): nothing computed ahead survives.
+// keep_iterate: the caller still needs the current iterate in v[0].
+int forget_carry(mgx_plan *p, bool keep_iterate = true)
+{
+    int rc = MGX_OK;
+    if (p->lazy && keep_iterate) rc = materialize(p);
+    p->lazy = false;
+    p->carry_valid = false;
+    p->last_valid = false;
+    p->streak = 0;
+    return rc;
 }
 
 // One V(Ndown,Nup) cycle, one kernel per reference operator:
@@ -811,16 +885,28 @@ size_t mgx_plan_bytes(const mgx_plan *p) { return p ? p->bytes : 0; }
 
 double *mgx_plan_f_dev(mgx_plan *p) { return p ? p->lv[0].f : nullptr; }
 
-double *mgx_plan_v_dev(mgx_plan *p) { return p ? p->lv[0].v[0] : nullptr; }
+double *mgx_plan_v_dev(mgx_plan *p)
+{
+    if (!p) return nullptr;
+    DeviceScope on_plan_device(p);
+    if (materialize(p) != MGX_OK) return nullptr;
+    return p->lv[0].v[0];
+}
 
 int mgx_plan_commit(mgx_plan *p)
 {
     DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_commit: null plan");
     Level &L = p->lv[0];
+    {
+        const int rc = forget_carry(p);
+        if (rc) return rc;
+    }
     L.cur = 0;
-    // both ping-pong buffers must carry the same Dirichlet boundary values
+    // both ping-pong buffers must carry the same Dirichlet boundary values, and so must the
+    // third array a call's closing launch may write the iterate to
     HIP_TRY(hipMemcpyAsync(L.v[1], L.v[0], sizeof(double) * L.n(), hipMemcpyDeviceToDevice, p->stream));
+    if (p->carry_capable && p->schedule == MGX_SCHEDULE_FUSED) return copy_boundary(p->r, L.v[0], L.m, p->stream);
     return MGX_OK;
 }
 
@@ -865,6 +951,10 @@ int mgx_plan_set_dev(mgx_plan *p, const double *f_dev, const double *v_dev)
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_set_dev: null plan");
     Level &L = p->lv[0];
     const size_t nb = sizeof(double) * L.n();
+    {
+        const int rc = forget_carry(p, v_dev == nullptr);
+        if (rc) return rc;
+    }
     if (f_dev) HIP_TRY(hipMemcpyAsync(L.f, f_dev, nb, hipMemcpyDeviceToDevice, p->stream));
     if (v_dev) HIP_TRY(hipMemcpyAsync(L.v[0], v_dev, nb, hipMemcpyDeviceToDevice, p->stream));
     return mgx_plan_commit(p);
@@ -874,6 +964,10 @@ int mgx_plan_get_dev(mgx_plan *p, double *v_dev)
 {
     DeviceScope on_plan_device(p);
     if (!p || !v_dev) return fail(MGX_ERR_ARG, "mgx_plan_get_dev: null argument");
+    {
+        const int rc = materialize(p);
+        if (rc) return rc;
+    }
     Level &L = p->lv[0];
     HIP_TRY(hipMemcpyAsync(v_dev, L.v[0], sizeof(double) * L.n(), hipMemcpyDeviceToDevice, p->stream));
     return MGX_OK;
@@ -884,6 +978,10 @@ int mgx_plan_upload(mgx_plan *p, const double *f_host, const double *v_host)
     DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_upload: null plan");
     Level &L = p->lv[0];
+    {
+        const int rc = forget_carry(p, v_host == nullptr);
+        if (rc) return rc;
+    }
     if (f_host) HIP_TRY(host_to_device(L.f, f_host, L.n(), p->stream));
     if (v_host) HIP_TRY(host_to_device(L.v[0], v_host, L.n(), p->stream));
     int rc = mgx_plan_commit(p);
@@ -899,6 +997,7 @@ int mgx_plan_upload_boundary(mgx_plan *p, const double *v_host)
     Level &L = p->lv[0];
     const size_t m = (size_t)L.m, col = sizeof(double) * m;
     hipStream_t s = p->stream;
+    (void)forget_carry(p, false);
     HIP_TRY(hipMemsetAsync(L.v[0], 0, sizeof(double) * L.n(), s));
     // columns 0 and m-1 are contiguous; rows 0 and m-1 are one double per column
     HIP_TRY(hipMemcpyAsync(L.v[0], v_host, col, hipMemcpyHostToDevice, s));
@@ -923,6 +1022,10 @@ int mgx_plan_download(mgx_plan *p, double *v_host)
 {
     DeviceScope on_plan_device(p);
     if (!p || !v_host) return fail(MGX_ERR_ARG, "mgx_plan_download: null argument");
+    {
+        const int rc = materialize(p);
+        if (rc) return rc;
+    }
     Level &L = p->lv[0];
     HIP_TRY(device_to_host(v_host, L.v[0], L.n(), p->stream));
     return MGX_OK;
@@ -941,11 +1044,46 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
     Level &L0 = p->lv[0];
     const SweepCoef c0 = make_coef(L0.dx, omega);
     HIP_TRY(hipMemsetAsync(p->slots, 0, sizeof(unsigned long long) * (size_t)(Nv + 1), s));
+    // Carry between calls (see mgx_plan::carry_valid): does this call continue the previous one,
+    // does it start from what that call left, and does it leave the same for the next?
+    const bool can_carry = p->carry_capable && p->schedule == MGX_SCHEDULE_FUSED && !pure_jacobi && p->depth > 0 &&
+                           Ndown >= 1 && Ndown + Nup <= STREAM_MAX_SWEEPS;
+    bool use_carry = false, make_carry = false;
+    {
+        const bool cont = Nv > 0 && can_carry && p->last_valid && p->last_Ndown == Ndown && p->last_Nup == Nup &&
+                          p->last_omega == omega;
+        if (!cont) {  // anything else needs the iterate itself in v[0]
+            rc = materialize(p);
+            if (rc) return rc;
+        }
+        if (Nv > 0) {
+            use_carry = cont && (p->lazy || p->carry_valid);
+            p->streak = cont ? p->streak + 1 : 0;
+            make_carry = can_carry && (p->force_carry || p->streak >= 2);
+        }
+    }
+    if (use_carry) {
+        // the previous call's closing launch already ran this call's opening down leg: the swept
+        // iterate is in v[0] (or, once somebody asked for the end-of-cycle iterate, in r), its
+        // coarse right-hand side in place, its norm known
+        HIP_TRY(hipMemcpyAsync(p->slots, &p->carry_key, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+        if (p->lazy) {
+            L0.cur = 0;
+        } else {
+            std::swap(L0.v[1], p->r);
+            L0.cur = 1;
+        }
+    }
+    if (Nv > 0) {
+        p->lazy = false;
+        p->carry_valid = false;  // consumed, or left behind by a call with other parameters
+        p->last_valid = false;   // until this call has gone through
+    }
     // main.cpp:307.  When the first cycle opens with a fused level-0 down leg, that launch
     // takes the norm of the initial residual along (one pass over v and f saved per call).
     const bool norm0_in_down = p->schedule == MGX_SCHEDULE_FUSED && !pure_jacobi && p->depth > 0 && Nv > 0 &&
                                Ndown <= STREAM_MAX_SWEEPS;
-    if (norm0_in_down) {
+    if (norm0_in_down || use_carry) {
         // nothing here
     } else if (p->schedule == MGX_SCHEDULE_FUSED) {  // the streaming kernel's 16-byte loads: 0.79 vs 1.09 ms at 16385^2
         StreamArgs A = level_args(L0, nullptr, omega);
@@ -965,10 +1103,13 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
                 // lean: the previous cycle's level-0 launch already did this cycle's down leg
                 const bool lean = cx.lean() && (Ndown + Nup) >= 1;
                 rc = MGX_OK;
-                if (iter == 0 || !lean) rc = fused_down(p, 0, cx, (iter == 0 && norm0_in_down) ? p->slots + 0 : nullptr);
+                const bool opened = iter == 0 && use_carry;  // the down leg came with the previous call
+                if ((iter == 0 || !lean) && !opened)
+                    rc = fused_down(p, 0, cx, (iter == 0 && norm0_in_down) ? p->slots + 0 : nullptr);
                 if (!rc) rc = fused_coarse_legs(p, cx);
-                if (!rc && iter == 0) rc = normalize_boundary(p);  // later cycles find it done
-                if (!rc) rc = fused_up(p, 0, cx, slot, lean && iter + 1 < Nv);
+                if (!rc && iter == 0 && !opened) rc = normalize_boundary(p);  // later cycles find it done
+                const bool closing = iter + 1 == Nv && make_carry;  // leave the next call's down leg behind
+                if (!rc) rc = fused_up(p, 0, cx, slot, lean && (iter + 1 < Nv || closing));
                 norm_done = true;
             } else if (!pure_jacobi) {
                 rc = vcycle_fused(p, Ndown, Nup, omega, slot);
@@ -991,11 +1132,22 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
             LAUNCH(p, 0, MGX_KERNEL_RESNORM, launch_residual_norm(L0.v[L0.cur], L0.f, L0.m, 1, L0.m - 1, c0, slot, s));
         HIP_TRY(hipEventRecord(p->events[iter + 1], s));
     }
-    if (L0.cur != 0) {  // the buffer that holds the solution becomes the one mgx_plan_v_dev() names
+    if (L0.cur != 0) {  // the buffer written last becomes v[0]
         std::swap(L0.v[0], L0.v[1]);
         L0.cur = 0;
     }
+    // (after a closing up+down launch v[0] is the swept iterate and v[1] that launch's input:
+    // the end-of-cycle iterate mgx_plan_v_dev() promises is made from them when asked for)
     HIP_TRY(hipStreamSynchronize(s));
+    if (Nv > 0 && can_carry) {
+        p->last_valid = true;
+        p->last_Ndown = Ndown;
+        p->last_Nup = Nup;
+        p->last_omega = omega;
+        p->lazy = make_carry;
+        if (make_carry)
+            HIP_TRY(hipMemcpy(&p->carry_key, p->slots + Nv, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
     std::vector<double> relax_s;  // stepwise: seconds inside relax() per cycle
     if (times && p->schedule == MGX_SCHEDULE_STEPWISE) {
         relax_s.assign((size_t)Nv, 0.0);
@@ -1041,7 +1193,9 @@ int mgx_plan_cycles_until(mgx_plan *p, int max_cycles, int Ndown, int Nup, doubl
     while (true) {
         const int n = std::min(batch, max_cycles - done);
         // (n == 0 only when max_cycles == 0: the call still yields the initial norm)
+        p->force_carry = true;  // more batches are likely to follow: leave each one's successor its down leg
         const int rc = mgx_plan_cycles(p, n, Ndown, Nup, omega, 0, rn.data(), tm.data());
+        p->force_carry = false;
         if (rc) return rc;
         if (done == 0) {
             r0 = rn[0];
@@ -1108,6 +1262,13 @@ int mgx_plan_tune(mgx_plan *p, int Ndown, int Nup, double omega)
     // three cycles visit every level-0 launch of a run (first down leg, up+down, last up leg)
     // with the measurement forced; the iterate is put back afterwards (p->r is idle in this
     // schedule), coarse levels are rebuilt by every cycle anyway
+    // (r is this call's keep buffer: nothing may be carried in it or written to it meanwhile)
+    {
+        const int rc = forget_carry(p);
+        if (rc) return rc;
+    }
+    const bool capable = p->carry_capable;
+    p->carry_capable = false;
     HIP_TRY(hipMemcpyAsync(p->r, L0.v[0], nb, hipMemcpyDeviceToDevice, p->stream));
     const bool was = set_tune_now(true);
     const int prof = p->profile;
@@ -1115,9 +1276,14 @@ int mgx_plan_tune(mgx_plan *p, int Ndown, int Nup, double omega)
     const int rc = mgx_plan_cycles(p, 3, Ndown, Nup, omega, 0, nullptr, nullptr);
     p->profile = prof;
     set_tune_now(was);
-    if (rc) return rc;
+    p->carry_capable = capable;
+    // the caller's iterate goes back whether or not the cycles went through (the commit also
+    // resets the ping-pong index a failed call may have left on the second buffer)
+    std::string why;
+    if (rc) why = mgx_last_error();
     HIP_TRY(hipMemcpyAsync(L0.v[0], p->r, nb, hipMemcpyDeviceToDevice, p->stream));
     const int rc2 = mgx_plan_commit(p);
+    if (rc) return fail(rc, "%s", why.c_str());
     if (rc2) return rc2;
     HIP_TRY(hipStreamSynchronize(p->stream));
     return MGX_OK;
@@ -1144,6 +1310,10 @@ int mgx_plan_fmg(mgx_plan *p, int ncyc, int Ndown, int Nup, double omega, double
     DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_fmg: null plan");
     if (ncyc < 0 || Ndown < 0 || Nup < 0) return fail(MGX_ERR_ARG, "mgx_plan_fmg: negative count");
+    {
+        const int rc = forget_carry(p);
+        if (rc) return rc;
+    }
     hipStream_t s = p->stream;
     const int depth = p->depth;
     // right-hand side and Dirichlet values of every level
@@ -1191,6 +1361,7 @@ int mgx_plan_fmg(mgx_plan *p, int ncyc, int Ndown, int Nup, double omega, double
         view.mid_nl_up = p->mid_nl_up;
         view.lv.assign(p->lv.begin() + l, p->lv.end());
         view.r = p->r;
+        view.carry_capable = false;
         view.slots = p->slots;
         view.nslots = p->nslots;
         view.events.swap(p->events);
@@ -1239,9 +1410,13 @@ int mgx_solve2d(const double *f, double *v, int m, int n, double dx,
         // A big guess is usually zeros inside a boundary (main.cpp:420-439 passes exactly that).
         // Host threads look while f is on its way up; if it is so, only the boundary follows,
         // otherwise the array (a guess with data ends the look at once).
-        std::future<bool> zero = std::async(std::launch::async, host_interior_is_zero, v, m);
+        std::future<bool> zero;
+        try {
+            zero = std::async(std::launch::async, host_interior_is_zero, v, m);
+        } catch (...) {  // no thread to be had: look after the upload instead of beside it
+        }
         rc = mgx_plan_upload(p, f, nullptr);
-        const bool z = zero.get();
+        const bool z = zero.valid() ? zero.get() : host_interior_is_zero(v, m);
         if (!rc) rc = z ? mgx_plan_upload_boundary(p, v) : mgx_plan_upload(p, nullptr, v);
     } else {
         rc = mgx_plan_upload(p, f, v);
@@ -1526,6 +1701,10 @@ int mgx_plan_vcycle_async(mgx_plan *p, int Ndown, int Nup, double omega, int zer
     DeviceScope on_plan_device(p);
     if (!p) return fail(MGX_ERR_ARG, "mgx_plan_vcycle_async: null plan");
     if (Ndown < 0 || Nup < 0) return fail(MGX_ERR_ARG, "mgx_plan_vcycle_async: negative count");
+    {
+        const int rc = forget_carry(p);
+        if (rc) return rc;
+    }
     if (zero_guess && p->schedule != MGX_SCHEDULE_FUSED) {
         // the stepwise schedule reads the iterate: make it zero in memory
         Level &L = p->lv[0];

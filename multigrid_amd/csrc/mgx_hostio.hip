@@ -67,6 +67,26 @@ int io_threads()
     return n;
 }
 
+// task(t) for t = 0..n-1, each on a thread of its own where one can be created; a task whose
+// thread cannot be created (std::system_error must not cross the C ABI) runs on the calling
+// thread after that thread's own share.  The tasks are independent of each other.
+template <class F>
+void run_tasks(int n, F task)
+{
+    std::vector<std::thread> th;
+    std::vector<int> here;
+    for (int t = 1; t < n; t++) {
+        try {
+            th.emplace_back(task, t);
+        } catch (...) {
+            here.push_back(t);
+        }
+    }
+    task(0);
+    for (int t : here) task(t);
+    for (std::thread &x : th) x.join();
+}
+
 // pinned staging buffers, allocated on first use (false: none, use plain copies)
 bool ensure_pool(Staging &P)
 {
@@ -74,18 +94,15 @@ bool ensure_pool(Staging &P)
     P.tried = true;
     P.nthreads = io_threads();
     // page-locking is slow and serial per call: let every thread lock its own pair
-    std::vector<std::thread> th;
     std::vector<int> bad((size_t)P.nthreads, 0);
-    for (int t = 0; t < P.nthreads; t++)
-        th.emplace_back([&P, &bad, t] {
-            for (int k = 0; k < 2; k++)
-                if (hipHostMalloc(&P.buf[t][k], CHUNK_BYTES, hipHostMallocPortable) != hipSuccess) {
-                    (void)hipGetLastError();
-                    P.buf[t][k] = nullptr;
-                    bad[(size_t)t] = 1;
-                }
-        });
-    for (std::thread &x : th) x.join();
+    run_tasks(P.nthreads, [&P, &bad](int t) {
+        for (int k = 0; k < 2; k++)
+            if (hipHostMalloc(&P.buf[t][k], CHUNK_BYTES, hipHostMallocPortable) != hipSuccess) {
+                (void)hipGetLastError();
+                P.buf[t][k] = nullptr;
+                bad[(size_t)t] = 1;
+            }
+    });
     bool ok = true;
     for (int b : bad) ok = ok && !b;
     if (!ok) {
@@ -174,11 +191,7 @@ hipError_t staged(bool to_device, void *dev, void *host, size_t nbytes, hipStrea
     if (e != hipSuccess) return e;
     const int T = P.nthreads;
     std::vector<Worker> w((size_t)T);
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++)
-        th.emplace_back(run_worker, t, T, device, to_device, (char *)dev, (char *)host, nbytes, P.buf[t], &w[t]);
-    run_worker(0, T, device, to_device, (char *)dev, (char *)host, nbytes, P.buf[0], &w[0]);
-    for (std::thread &x : th) x.join();
+    run_tasks(T, [&](int t) { run_worker(t, T, device, to_device, (char *)dev, (char *)host, nbytes, P.buf[t], &w[t]); });
     for (const Worker &x : w)
         if (x.err != hipSuccess) return x.err;
     return hipSuccess;
@@ -214,10 +227,7 @@ bool host_interior_is_zero(const double *v, int m)
             if (acc) nonzero.store(true, std::memory_order_relaxed);
         }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back(scan, t);
-    scan(0);
-    for (std::thread &x : th) x.join();
+    run_tasks(T, scan);
     return !nonzero.load();
 }
 

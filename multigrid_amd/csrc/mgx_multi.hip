@@ -165,6 +165,10 @@ struct mgx_mplan {
     std::vector<std::unique_ptr<Slab>> slabs;
     std::unique_ptr<std::atomic<long>[]> posted, pulled, tposted;
     std::atomic<int> failed{0};
+    // Set when a call failed part-way: the slabs' hand-shake counters, ping-pong indices and
+    // streams are then out of step with each other, so every entry point but destroy refuses.
+    int poisoned = 0;
+    std::string poison_msg;
     int profile = 0;
     double prof_ms[MGX_KERNEL_COUNT] = {0};
     long prof_n[MGX_KERNEL_COUNT] = {0};
@@ -348,6 +352,11 @@ int exchange_begin(Slab &S, const std::vector<XItem> &items)
     const long x = ++S.xcount;
     S.pending = items;
     if (S.rank == 0) mp->nexchanges++;
+    // test hook: slab MGX_TEST_FAIL_SLAB gives up at the second exchange of a call's life, the way
+    // a HIP error would, so that the other slabs' reaction and the plan's refusal can be tested
+    if (const char *e = getenv("MGX_TEST_FAIL_SLAB"))
+        if (*e && atoi(e) == S.rank && x >= 2)
+            return slab_fail(S, MGX_ERR_STATE, "slab %d: failure injected by MGX_TEST_FAIL_SLAB", S.rank);
     S_HIP(S, hipEventRecord(S.ready[x & 1], S.compute));
     mp->posted[S.rank].store(x, std::memory_order_release);
     return MGX_OK;
@@ -505,6 +514,9 @@ int chain(Slab &S, int level, int kid, int pro, int ns, int res, int zero_in, do
 int normalize_boundary(Slab &S)
 {
     SLevel &L = S.lv[S.top];
+    // it rewrites rows 0 and m-1 of every stored column, also of the columns the neighbours
+    // are pulling in the exchange posted last: after their pulls
+    S_TRY(fence_pulls(S));
     for (int k = 0; k < 2; k++)
         S_HIP(S, launch_slab_boundary_plus_zero(L.v[k], L.m, L.ncols, L.jfix_lo, L.jfix_hi, S.compute));
     return MGX_OK;
@@ -1023,35 +1035,69 @@ int level_sizes(int m, int coarsest, std::vector<int> &dims)
     return MGX_OK;
 }
 
-template <class F>
-int on_every_slab(mgx_mplan *mp, F fn)
+int poisoned_fail(const mgx_mplan *mp, const char *who)
 {
-    // one thread per slab; the calling thread's current device is left as it was
+    return api_fail(MGX_ERR_STATE, "%s: an earlier call on this partitioned plan failed (%s); its slabs are out of step, "
+                                   "destroy the plan", who, mp->poison_msg.c_str());
+}
+
+// Run fn on every slab, one thread per slab; the calling thread's current device is left as
+// it was.  `sticky`: a failure leaves the slabs out of step with each other (counters,
+// ping-pong indices, work still queued), so the plan is marked and refuses further calls.
+template <class F>
+int on_every_slab(mgx_mplan *mp, F fn, bool sticky = true)
+{
     std::vector<std::thread> th;
-    for (int g = 1; g < mp->R; g++) th.emplace_back([mp, g, &fn] { (void)fn(*mp->slabs[g]); });
+    int spawned = 1;
+    try {
+        for (int g = 1; g < mp->R; g++) {
+            th.emplace_back([mp, g, &fn] { (void)fn(*mp->slabs[g]); });
+            spawned++;
+        }
+    } catch (...) {
+        // a thread could not be created: the slabs that did start must not wait for the others
+        mp->failed.store(1, std::memory_order_release);
+    }
     int prev = -1;
     const bool have_prev = hipGetDevice(&prev) == hipSuccess;
     (void)fn(*mp->slabs[0]);
     for (std::thread &t : th) t.join();
     if (have_prev) (void)hipSetDevice(prev);
-    for (int g = 0; g < mp->R; g++)
-        if (mp->slabs[g]->rc != MGX_OK) {
-            const int rc = mp->slabs[g]->rc;
-            const std::string msg = mp->slabs[g]->err;
-            for (int k = 0; k < mp->R; k++) {
-                mp->slabs[k]->rc = MGX_OK;
-                mp->slabs[k]->err.clear();
-            }
-            mp->failed.store(0);
-            return api_fail(rc, "%s", msg.c_str());
-        }
-    if (mp->failed.load()) {
-        const int why = mp->failed.load();
-        mp->failed.store(0);
-        return api_fail(MGX_ERR_STATE, why == 2 ? "a slab's hand-shake with its neighbour timed out (MGX_MPLAN_TIMEOUT)"
-                                                : "a slab thread gave up");
+    int rc = MGX_OK;
+    std::string msg;
+    if (spawned < mp->R) {
+        rc = MGX_ERR_NOMEM;
+        msg = "a slab's host thread could not be created";
     }
-    return MGX_OK;
+    for (int g = 0; g < mp->R && rc == MGX_OK; g++)
+        if (mp->slabs[g]->rc != MGX_OK) {
+            rc = mp->slabs[g]->rc;
+            msg = mp->slabs[g]->err;
+        }
+    if (rc == MGX_OK && mp->failed.load()) {
+        rc = MGX_ERR_STATE;
+        msg = mp->failed.load() == 2 ? "a slab's hand-shake with its neighbour timed out (MGX_MPLAN_TIMEOUT)"
+                                     : "a slab thread gave up";
+    }
+    for (int k = 0; k < mp->R; k++) {
+        mp->slabs[k]->rc = MGX_OK;
+        mp->slabs[k]->err.clear();
+    }
+    mp->failed.store(0);
+    if (rc == MGX_OK) return MGX_OK;
+    if (sticky) {
+        // let what the slabs did enqueue drain, so that nothing of this call is still running
+        // when the caller reacts (the plan stays unusable: the slabs disagree on where they are)
+        for (auto &S : mp->slabs)
+            if (hipSetDevice(S->dev) == hipSuccess) {
+                if (S->compute) (void)hipStreamSynchronize(S->compute);
+                if (S->comm) (void)hipStreamSynchronize(S->comm);
+            }
+        if (have_prev) (void)hipSetDevice(prev);
+        mp->poisoned = 1;
+        mp->poison_msg = msg;
+    }
+    return api_fail(rc, "%s", msg.c_str());
 }
 
 } // namespace
@@ -1184,6 +1230,13 @@ int mgx_mplan_destroy(mgx_mplan *mp)
     if (!mp) return MGX_OK;
     int prev = -1;
     (void)hipGetDevice(&prev);
+    // every slab's streams first: a peer copy queued on one slab's stream reads another slab's
+    // arrays, so nothing may be freed while any stream still holds work
+    for (auto &S : mp->slabs)
+        if (hipSetDevice(S->dev) == hipSuccess) {
+            if (S->compute) (void)hipStreamSynchronize(S->compute);
+            if (S->comm) (void)hipStreamSynchronize(S->comm);
+        }
     for (auto &S : mp->slabs) destroy_slab(*S);
     if (prev >= 0) (void)hipSetDevice(prev);
     delete mp;
@@ -1223,6 +1276,7 @@ int mgx_mplan_slab(mgx_mplan *mp, int slab, mgx_slab_info *info)
 int mgx_mplan_commit(mgx_mplan *mp)
 {
     if (!mp) return api_fail(MGX_ERR_ARG, "mgx_mplan_commit: null plan");
+    if (mp->poisoned) return poisoned_fail(mp, "mgx_mplan_commit");
     return on_every_slab(mp, [](Slab &S) {
         S_HIP(S, hipSetDevice(S.dev));
         SLevel &L = S.lv[0];
@@ -1236,6 +1290,7 @@ int mgx_mplan_commit(mgx_mplan *mp)
 int mgx_mplan_upload(mgx_mplan *mp, const double *f_host, const double *v_host)
 {
     if (!mp) return api_fail(MGX_ERR_ARG, "mgx_mplan_upload: null plan");
+    if (mp->poisoned) return poisoned_fail(mp, "mgx_mplan_upload");
     return on_every_slab(mp, [f_host, v_host](Slab &S) {
         S_HIP(S, hipSetDevice(S.dev));
         SLevel &L = S.lv[0];
@@ -1253,6 +1308,7 @@ int mgx_mplan_upload(mgx_mplan *mp, const double *f_host, const double *v_host)
 int mgx_mplan_download(mgx_mplan *mp, double *v_host)
 {
     if (!mp || !v_host) return api_fail(MGX_ERR_ARG, "mgx_mplan_download: null argument");
+    if (mp->poisoned) return poisoned_fail(mp, "mgx_mplan_download");
     return on_every_slab(mp, [v_host](Slab &S) {
         S_HIP(S, hipSetDevice(S.dev));
         SLevel &L = S.lv[0];
@@ -1328,6 +1384,7 @@ int mgx_mplan_cycles(mgx_mplan *mp, int Nv, int Ndown, int Nup, double omega, in
                      double *times)
 {
     if (!mp) return api_fail(MGX_ERR_ARG, "mgx_mplan_cycles: null plan");
+    if (mp->poisoned) return poisoned_fail(mp, "mgx_mplan_cycles");
     if (Nv < 0 || Ndown < 0 || Nup < 0) return api_fail(MGX_ERR_ARG, "mgx_mplan_cycles: negative count");
     CycleArgs a;
     a.Nv = Nv;
@@ -1341,6 +1398,7 @@ int mgx_mplan_cycles(mgx_mplan *mp, int Nv, int Ndown, int Nup, double omega, in
 int mgx_mplan_fmg(mgx_mplan *mp, int ncyc, int Ndown, int Nup, double omega, double *resnorms, double *times)
 {
     if (!mp) return api_fail(MGX_ERR_ARG, "mgx_mplan_fmg: null plan");
+    if (mp->poisoned) return poisoned_fail(mp, "mgx_mplan_fmg");
     if (ncyc < 0 || Ndown < 0 || Nup < 0) return api_fail(MGX_ERR_ARG, "mgx_mplan_fmg: negative count");
     CycleArgs a;
     a.Nv = ncyc;
@@ -1354,41 +1412,58 @@ int mgx_mplan_fmg(mgx_mplan *mp, int ncyc, int Ndown, int Nup, double omega, dou
 int mgx_mplan_tune(mgx_mplan *mp, int Ndown, int Nup, double omega)
 {
     if (!mp) return api_fail(MGX_ERR_ARG, "mgx_mplan_tune: null plan");
+    if (mp->poisoned) return poisoned_fail(mp, "mgx_mplan_tune");
     if (Ndown < 0 || Nup < 0) return api_fail(MGX_ERR_ARG, "mgx_mplan_tune: negative count");
     // keep the level-0 iterate, run three cycles with the measurement forced, put it back
     std::vector<double *> keep((size_t)mp->R, nullptr);
+    auto free_keep = [&] {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        for (int g = 0; g < mp->R; g++)
+            if (keep[g] && hipSetDevice(mp->slabs[g]->dev) == hipSuccess) {
+                (void)hipFree(keep[g]);
+                keep[g] = nullptr;
+            }
+        if (prev >= 0) (void)hipSetDevice(prev);
+    };
+    // (a failed allocation leaves the slabs in step: nothing was enqueued but copies out of v)
     int rc = on_every_slab(mp, [&keep](Slab &S) {
         S_HIP(S, hipSetDevice(S.dev));
         SLevel &L = S.lv[0];
         S_HIP(S, hipMalloc((void **)&keep[S.rank], L.bytes()));
         S_HIP(S, hipMemcpyAsync(keep[S.rank], L.v[L.cur], L.bytes(), hipMemcpyDeviceToDevice, S.compute));
+        S_HIP(S, hipStreamSynchronize(S.compute));
         return (int)MGX_OK;
-    });
-    if (rc == MGX_OK) {
-        CycleArgs a;
-        a.Nv = 3;
-        a.Ndown = Ndown;
-        a.Nup = Nup;
-        a.omega = omega;
-        a.tune = true;
-        const int prof = mp->profile;
-        mp->profile = 0;
-        rc = mplan_run(mp, a, nullptr, nullptr);
-        mp->profile = prof;
+    }, false);
+    if (rc != MGX_OK) {
+        free_keep();
+        return rc;
     }
-    const int rc2 = on_every_slab(mp, [&keep](Slab &S) {
+    CycleArgs a;
+    a.Nv = 3;
+    a.Ndown = Ndown;
+    a.Nup = Nup;
+    a.omega = omega;
+    a.tune = true;
+    const int prof = mp->profile;
+    mp->profile = 0;
+    rc = mplan_run(mp, a, nullptr, nullptr);
+    mp->profile = prof;
+    if (rc != MGX_OK) {  // the plan is poisoned; nothing to put back into
+        free_keep();
+        return rc;
+    }
+    rc = on_every_slab(mp, [&keep](Slab &S) {
         S_HIP(S, hipSetDevice(S.dev));
         SLevel &L = S.lv[0];
-        if (keep[S.rank]) {
-            S_HIP(S, hipMemcpyAsync(L.v[0], keep[S.rank], L.bytes(), hipMemcpyDeviceToDevice, S.compute));
-            S_HIP(S, hipMemcpyAsync(L.v[1], keep[S.rank], L.bytes(), hipMemcpyDeviceToDevice, S.compute));
-            L.cur = 0;
-            S_HIP(S, hipStreamSynchronize(S.compute));
-            S_HIP(S, hipFree(keep[S.rank]));
-        }
+        S_HIP(S, hipMemcpyAsync(L.v[0], keep[S.rank], L.bytes(), hipMemcpyDeviceToDevice, S.compute));
+        S_HIP(S, hipMemcpyAsync(L.v[1], keep[S.rank], L.bytes(), hipMemcpyDeviceToDevice, S.compute));
+        L.cur = 0;
+        S_HIP(S, hipStreamSynchronize(S.compute));
         return (int)MGX_OK;
     });
-    return rc != MGX_OK ? rc : rc2;
+    free_keep();
+    return rc;
 }
 
 int mgx_mplan_profile(mgx_mplan *mp, int enable)

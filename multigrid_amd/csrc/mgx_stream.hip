@@ -34,9 +34,10 @@
 // NS+2 columns and never touches memory in between.  North/south neighbours
 // (j-1, j+1) are the lane's own registers of the previous/next column;
 // west/east neighbours (i-1, i+1) are the lane's other row or one cross-lane
-// shift.  Waves are independent: no LDS, no barriers.  Strips overlap by the
-// halo the pipeline consumes (NS+2 rows below, NS+1 above), chunks by the same
-// number of columns; the overlap is recomputed, not communicated.
+// shift.  No LDS; the waves of a workgroup meet at an s_barrier every few columns
+// only so that they stay close enough for their shared halo rows to hit in L2.
+// Strips overlap by the halo the pipeline consumes (NS+2 rows below, NS+1 above),
+// chunks by the same number of columns; the overlap is recomputed, not communicated.
 //
 // The march is unrolled by two so that the parity of the column (which decides
 // the interpolation formula and when a coarse column is complete) is static,
@@ -218,17 +219,17 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
         }
         return r;
     };
-    auto store_col = [&](int j, const P2 &v) {
+    auto store_to = [&](double *__restrict__ base, int j, const P2 &v) {
         if (EDGE) {
 #if MGX_NT_STORE
-            if (owna) __builtin_nontemporal_store(v.a, po + (size_t)j * ld);
-            if (ownb) __builtin_nontemporal_store(v.b, po + (size_t)j * ld + 1);
+            if (owna) __builtin_nontemporal_store(v.a, base + (size_t)j * ld);
+            if (ownb) __builtin_nontemporal_store(v.b, base + (size_t)j * ld + 1);
 #else
-            if (owna) po[(size_t)j * ld] = v.a;
-            if (ownb) po[(size_t)j * ld + 1] = v.b;
+            if (owna) base[(size_t)j * ld] = v.a;
+            if (ownb) base[(size_t)j * ld + 1] = v.b;
 #endif
         } else if (owna) {
-            double *q = po + (size_t)j * ld;
+            double *q = base + (size_t)j * ld;
 #if MGX_NT_STORE
             __builtin_nontemporal_store(v.a, q);
             __builtin_nontemporal_store(v.b, q + 1);
@@ -238,6 +239,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
 #endif
         }
     };
+    auto store_col = [&](int j, const P2 &v) { store_to(po, j, v); };
 
     // ---- prolongation state (PRO) -------------------------------------------
     // The correction is added to stage PA, whose newest column at input column
@@ -786,7 +788,14 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
         // columns, each marching its 11 halo columns too.  Longer chunks move fewer bytes, fewer
         // chunks march longer: measured.
         const int width = std::max(A.jhi - A.jlo, A.jhi2 - A.jlo2);
+        static const int edge_cj = env_int("MGX_EDGE_CJ", 0);  // experiment knob: a fixed chunk length, unmeasured
+        if (edge_cj > 0) {
+            cands[0].nwv = 4;
+            cands[0].CJ = edge_cj + (edge_cj & 1);
+            ncands = 1;
+        }
         for (int div : {2, 4, 6, 8, 12}) {
+            if (edge_cj > 0) break;
             LaunchShape c = plain;
             c.nwv = 4;
             c.CJ = (width + div - 1) / div;

@@ -109,6 +109,28 @@ def ref_lib():
 _OPS = None
 
 
+def _bind_ref_ops(path):
+    L = ctypes.CDLL(path)
+    i, d = ctypes.c_int, ctypes.c_double
+    L.ref_calc_norm.restype = d
+    L.ref_calc_norm.argtypes = [_dp, i]
+    L.ref_relax.restype = None
+    L.ref_relax.argtypes = [_dp, _dp, i, d, i, d]
+    L.ref_residual.restype = None
+    L.ref_residual.argtypes = [_dp, _dp, _dp, i, d]
+    L.ref_coarsen.restype = None
+    L.ref_coarsen.argtypes = [_dp, i, _dp, i]
+    L.ref_refine.restype = None
+    L.ref_refine.argtypes = [_dp, i, _dp, i]
+    L.ref_direct_solve.restype = None
+    L.ref_direct_solve.argtypes = [_dp, _dp, i, d]
+    L.ref_depth.restype = i
+    L.ref_depth.argtypes = [i, i]
+    L.ref_multigrid.restype = None
+    L.ref_multigrid.argtypes = [_dp, _dp, i, d, i, i, i, d, i, i, _dp, _dp]
+    return L
+
+
 def ref_ops():
     """The reference's own solver functions (main.cpp:147-357) compiled from the reference
     checkout into oracle/_ref/librefops.so (oracle/Makefile, oracle/ref_main_harness.cpp), or
@@ -118,36 +140,36 @@ def ref_ops():
         path = os.path.join(_HERE, "_ref", "librefops.so")
         if not os.path.exists(path):
             return None
-        L = ctypes.CDLL(path)
-        i, d = ctypes.c_int, ctypes.c_double
-        L.ref_calc_norm.restype = d
-        L.ref_calc_norm.argtypes = [_dp, i]
-        L.ref_relax.restype = None
-        L.ref_relax.argtypes = [_dp, _dp, i, d, i, d]
-        L.ref_residual.restype = None
-        L.ref_residual.argtypes = [_dp, _dp, _dp, i, d]
-        L.ref_coarsen.restype = None
-        L.ref_coarsen.argtypes = [_dp, i, _dp, i]
-        L.ref_refine.restype = None
-        L.ref_refine.argtypes = [_dp, i, _dp, i]
-        L.ref_direct_solve.restype = None
-        L.ref_direct_solve.argtypes = [_dp, _dp, i, d]
-        L.ref_depth.restype = i
-        L.ref_depth.argtypes = [i, i]
-        L.ref_multigrid.restype = None
-        L.ref_multigrid.argtypes = [_dp, _dp, i, d, i, i, i, d, i, i, _dp, _dp]
-        _OPS = L
+        _OPS = _bind_ref_ops(path)
     return _OPS
+
+
+_OPS_REL = None
+
+
+def ref_ops_release():
+    """TIMING ONLY: the same functions built with the reference's Release flags (-O3 -Ofast
+    -DNDEBUG, CMakeLists.txt:17) into oracle/_ref/librefops_release.so, or None.  Fast-math bits
+    are not the parity definition; nothing compares against this build."""
+    global _OPS_REL
+    if _OPS_REL is None:
+        path = os.path.join(_HERE, "_ref", "librefops_release.so")
+        if not os.path.exists(path):
+            return None
+        _OPS_REL = _bind_ref_ops(path)
+    return _OPS_REL
 
 
 class Ref:
     """numpy front end of ref_ops() with the same call shapes as this module's functions, so a
     test can run `O.relax(...)` and `O.Ref().relax(...)` side by side."""
 
-    def __init__(self):
-        self.L = ref_ops()
+    def __init__(self, release=False):
+        """release=True: the -Ofast build, for timing only."""
+        self.L = ref_ops_release() if release else ref_ops()
         if self.L is None:
-            raise RuntimeError("oracle/_ref/librefops.so not built (reference checkout absent)")
+            raise RuntimeError("oracle/_ref/librefops%s.so not built (reference checkout absent)"
+                               % ("_release" if release else ""))
 
     def calc_norm(self, r):
         r = _f64(r)

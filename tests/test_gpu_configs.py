@@ -311,6 +311,20 @@ def test_cycles_to_a_tolerance_257(mg, O, known, f_smooth_257):
     out, why = plan.cycles_until(0, 2, 2, 0.6, 1e-8)
     assert why == _lib.STOP_MAX_CYCLES and out.ResidualNorms.shape == (1,)
     plan.close()
+    # a cycle that converges slowly is not a floor: V(0,1) contracts by 0.72 per cycle and V(1,1)
+    # by 0.54, both far from the tolerance and from the rounding floor after 12 cycles -> the loop
+    # runs to max_cycles (a rule "no longer halves the norm" would stop them at cycle 4)
+    for (nd, nu) in ((0, 1), (1, 1)):
+        plan = mg.Plan(M, dx, 2)
+        plan.set(mg.to_device(f_smooth_257), mg.colmajor(M, M))
+        out, why = plan.cycles_until(12, nd, nu, 0.6, 1e-12, batch=1)
+        rn = out.ResidualNorms
+        assert why == _lib.STOP_MAX_CYCLES and len(rn) == 13, (why, rn)
+        assert 0.5 < rn[8] / rn[7] < 0.95          # slow, but still converging
+        ref_sol, ref_rn, _ = O.multigrid(f_smooth_257, np.zeros((M, M), order="F"), dx, 12, nd, nu, 0.6, 2)
+        assert_bits(rn, ref_rn, "ResNorms V(%d,%d) x12 in single-cycle calls" % (nd, nu))
+        assert_bits(mg.to_numpy(plan.get()), ref_sol, "Sol V(%d,%d) x12 in single-cycle calls" % (nd, nu))
+        plan.close()
 
 
 def test_32769_host_arrays_against_the_threaded_oracle(mg, O):
@@ -334,3 +348,44 @@ def test_32769_host_arrays_against_the_threaded_oracle(mg, O):
     out = mg.solve_host(f, v0, dx, 2, 2, 2, 0.6, 2)        # v0 is overwritten with the solution
     assert_bits(out.ResidualNorms, rn, "ResNorms 32769")
     assert np.array_equal(v0.view(np.uint64), sol.view(np.uint64)), "Sol 32769"
+
+
+def test_16385_single_cycle_calls_cost_what_one_long_call_costs(mg):
+    """The benchmark size driven one cycle per call (a caller's own tolerance loop): from the
+    third call on a call's closing launch carries the next call's opening down leg, so 24 calls
+    of one cycle take about as long as one call of 24 (two level-0 launches per cycle would be
+    +70 %), and give the same history and the same solution bits."""
+    import time
+    import torch
+    from multigrid_amd import rhs
+    M, N = 16385, 24
+    dx = 1.0 / (M - 1)
+    plan = mg.Plan(M, dx, 2)
+    f = rhs.random_torch(M)
+    zero = mg.colmajor(M, M)
+    plan.set(f, zero)
+    plan.tune(2, 2, 0.6)
+    for _ in range(4):
+        plan.cycles(1, 2, 2, 0.6)           # the closing launch's own launch shape gets measured here
+    plan.set(f, zero)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    one = plan.cycles(N, 2, 2, 0.6)
+    torch.cuda.synchronize()
+    t_one = time.perf_counter() - t0
+    fp_one = _fingerprint(mg, plan, M)
+    plan.set(f, zero)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hist = [plan.cycles(1, 2, 2, 0.6).ResidualNorms for _ in range(N)]
+    torch.cuda.synchronize()
+    t_many = time.perf_counter() - t0
+    fp_many = _fingerprint(mg, plan, M)
+    plan.close()
+    got = np.concatenate([hist[0]] + [h[1:] for h in hist[1:]])
+    print("16385^2: one call of %d cycles %.2f ms, %d calls of one cycle %.2f ms (x%.3f)"
+          % (N, t_one * 1e3, N, t_many * 1e3, t_many / t_one))
+    assert_bits(got, one.ResidualNorms, "ResNorms, 24 calls of one cycle")
+    assert all(h[0] == g[-1] for h, g in zip(hist[1:], hist[:-1]))
+    assert fp_one == fp_many
+    assert t_many < 1.12 * t_one

@@ -226,3 +226,133 @@ def test_full_multigrid_16385_over_four_slabs_equals_the_single_plan(mg):
                            want.t()[s.own_first:s.own_first + s.own_count].view(torch.int64))
     P.close()
     plan.close()
+
+
+def test_a_failed_call_poisons_the_plan(mg, monkeypatch):
+    """One slab gives up in the middle of a call (injected, the way a HIP error would): the other
+    slabs stop waiting for it, the call reports the failure, and from then on every entry point
+    but destroy refuses with MGX_ERR_STATE instead of running on counters and ping-pong indices
+    that no longer agree between the slabs."""
+    M = 513
+    f, v0 = _problem(M)
+    P = mg.MultiPlan(M, 1.0 / (M - 1), 2, nslabs=3, devices=[0] * 3, tail_m=65)
+    P.upload(f, v0)
+    ok = P.cycles(2, 2, 2, 0.6)
+    assert ok.ResidualNorms[2] < ok.ResidualNorms[0]
+    monkeypatch.setenv("MGX_TEST_FAIL_SLAB", "1")
+    with pytest.raises(mg.MgxError) as e:
+        P.cycles(3, 2, 2, 0.6)
+    assert e.value.code == -5 and "injected" in str(e.value)
+    monkeypatch.delenv("MGX_TEST_FAIL_SLAB")
+    for call in (lambda: P.cycles(1, 2, 2, 0.6), lambda: P.upload(f, v0), lambda: P.download(),
+                 lambda: P.fmg(1, 2, 2, 0.6), lambda: P.tune(2, 2, 0.6)):
+        with pytest.raises(mg.MgxError) as e:
+            call()
+        assert e.value.code == -5 and "earlier call" in str(e.value)
+    P.close()
+    # a fresh plan of the same shape works (nothing of the failed one lingers in the library)
+    P = mg.MultiPlan(M, 1.0 / (M - 1), 2, nslabs=3, devices=[0] * 3, tail_m=65)
+    P.upload(f, v0)
+    again = P.cycles(2, 2, 2, 0.6)
+    assert_bits(again.ResidualNorms, ok.ResidualNorms, "after a poisoned plan")
+    P.close()
+
+
+def test_random_partitioned_cases_small_budget():
+    """tools/fuzz_parity.py restricted to the partitioned plan (random slab counts 1-8, sweep
+    counts, split calls, full multigrid, odd hierarchies): about 150 cases or 100 seconds, every
+    one bit-identical to the oracle.  Keeps the threads' hand-shake schedule covered (a sweep of
+    this kind found a deadlock between slabs of different width)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, FUZZ_MODES="3,4", FUZZ_CASES="150", MGX_MPLAN_TIMEOUT="60")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "100", "20261112", "700"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0, tail
+    assert "bit-identical to the oracle" in tail
+
+
+def _free_hbm_gb():
+    import torch
+    return torch.cuda.mem_get_info()[0] / 1e9
+
+
+def _plan_and_slabs_agree(mg, M, coarsest, R, Nv, exact, fmg=0):
+    """A single plan and a partitioned plan of R slabs on the same device-generated right-hand
+    side: (history of the plan, history of the slabs, number of solution words that differ)."""
+    import torch
+    from multigrid_amd import _lib
+    from multigrid_amd.slab import _device_view
+    from multigrid_amd.solver import _DevPtr
+    from test_gpu_configs import _fill_plan_rhs
+    cs = mg.COARSE_EXACT if exact else mg.COARSE_REFERENCE
+    dx = 1.0 / (M - 1)
+    plan = mg.Plan(M, dx, coarsest, coarse_solve=cs)
+    _fill_plan_rhs(mg, plan, M)
+    ref = plan.fmg(fmg, 2, 2, 0.6) if fmg else plan.cycles(Nv, 2, 2, 0.6)
+    want = _device_view(_lib.load().mgx_plan_v_dev(plan._h), M, torch.device("cuda"))  # row k = column k
+    P = mg.MultiPlan(M, dx, coarsest, nslabs=R, devices=[0] * R, coarse_solve=cs)
+    P.set_random_rhs()
+    out = P.fmg(fmg, 2, 2, 0.6) if fmg else P.cycles(Nv, 2, 2, 0.6)
+    differ, worst = 0, 0.0
+    for k in range(R):
+        s = P.slab(k)
+        v = torch.as_tensor(_DevPtr(s.v_dev, (s.ncols, s.m)), device="cuda")
+        a = s.own_first - s.col_first
+        own, w = v[a:a + s.own_count], want[s.own_first:s.own_first + s.own_count]
+        differ += int((own.view(torch.int64) != w.view(torch.int64)).sum().item())
+        worst = max(worst, float((own - w).abs().max().item()))
+    scale = float(want.abs().max().item())
+    ndist, tail_m = P.ndist, P.tail_m
+    P.close()
+    plan.close()
+    del want
+    torch.cuda.empty_cache()
+    return ref.ResidualNorms, out.ResidualNorms, differ, worst / scale, ndist, tail_m
+
+
+def test_22529_over_two_slabs_like_the_weak_scaling_run(mg):
+    """The 2-GPU weak-scaling size at its partitioned shape: 22529 = 11*2^11+1 over two slabs,
+    coarsest 11.  With the reference's coarsest behaviour (the 12x12 grid left alone) the slabs
+    equal the single plan bit for bit; with the exact coarsest solve every slab's tail runs the
+    same sine-transform solve as the single plan's, so the bits are equal there too."""
+    if _free_hbm_gb() < 60:
+        pytest.skip("needs 60 GB of free HBM")
+    a, b, differ, _, ndist, tail_m = _plan_and_slabs_agree(mg, 22529, 11, 2, 3, exact=False)
+    assert ndist >= 4 and tail_m <= 1409
+    assert_bits(b, a, "ResNorms 22529 over 2 slabs")
+    assert differ == 0
+    a, b, differ, rel, _, _ = _plan_and_slabs_agree(mg, 22529, 11, 2, 12, exact=True)
+    from test_gpu_configs import _stop
+    assert _stop(a) == _stop(b)
+    assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * a[0]) and rel <= 1e-9
+    print("22529^2 over 2 slabs, exact coarsest solve: stop", _stop(b), "words that differ", differ, "rel", rel)
+
+
+def test_45057_over_eight_slabs_like_the_weak_scaling_run(mg):
+    """The 8-GPU weak-scaling size at its partitioned shape: 45057 = 11*2^12+1 over eight slabs
+    (all on this one GPU: 81 GB for the plan, 95 GB for the slabs, one after the other would not
+    do -- both are alive for the comparison, so it needs most of the card)."""
+    if _free_hbm_gb() < 200:
+        pytest.skip("needs 200 GB of free HBM")
+    a, b, differ, _, ndist, tail_m = _plan_and_slabs_agree(mg, 45057, 11, 8, 2, exact=False)
+    assert ndist >= 5
+    assert_bits(b, a, "ResNorms 45057 over 8 slabs")
+    assert differ == 0
+    a, b, differ, rel, _, _ = _plan_and_slabs_agree(mg, 45057, 11, 8, 6, exact=True)
+    assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * a[0]) and rel <= 1e-9
+    assert b[6] < 1e-3 * b[0]
+
+
+def test_full_multigrid_32769_over_four_slabs(mg):
+    """Full multigrid + V-cycles at 32769^2 (the configuration's size) over four slabs: the
+    history and every column equal mgx_plan_fmg on one device."""
+    if _free_hbm_gb() < 120:
+        pytest.skip("needs 120 GB of free HBM")
+    a, b, differ, _, ndist, tail_m = _plan_and_slabs_agree(mg, 32769, 2, 4, 0, exact=False, fmg=2)
+    assert ndist == 5 and tail_m == 1025
+    assert_bits(b, a, "FMG ResNorms 32769 over 4 slabs")
+    assert differ == 0

@@ -315,3 +315,53 @@ def test_host_arrays_through_the_staged_transfers(mg, O):
         out = mg.solve_host(f, v, dx, 1, 0, 1, 0.6, 2)
         assert_bits(out.ResidualNorms, rn_d, "ResNorms, guess with one entry %r" % val)
         assert_bits(v, sol_d, "Sol, guess with one entry %r" % val)
+
+
+def test_single_cycle_calls_carry_the_next_down_leg(mg, O):
+    """Calls of one cycle each (a caller's own tolerance loop): from the third such call on, a
+    call's closing launch also runs the next call's opening sweeps and restriction, and the next
+    call starts from there.  Whatever the pattern of calls -- parameters changed in between, the
+    iterate read, replaced or committed, zero-cycle calls, full multigrid in between -- histories
+    and solutions are the oracle's, bit for bit."""
+    M = 513
+    dx = 1.0 / (M - 1)
+    rng = np.random.default_rng(5)
+    f = np.asfortranarray(rng.standard_normal((M, M)))
+    v0 = np.zeros((M, M), order="F")
+    v0[0, :], v0[-1, :], v0[:, 0], v0[:, -1] = rng.standard_normal((4, M))
+    v0[0, 3] = v0[7, 0] = -0.0
+    plan = mg.Plan(M, dx, 2)
+    plan.set(mg.to_device(f), mg.to_device(v0))
+    ref_v = v0
+    hist = []
+
+    def run(n, nd, nu, om):
+        nonlocal ref_v
+        out = plan.cycles(n, nd, nu, om)
+        sol, rn, _ = O.multigrid(f, ref_v, dx, n, nd, nu, om, 2)
+        assert_bits(out.ResidualNorms, rn, "ResNorms of call %d: %d x V(%d,%d)" % (len(hist), n, nd, nu))
+        ref_v = sol
+        hist.append((n, nd, nu))
+        assert_bits(mg.to_numpy(plan.get()), ref_v, "Sol after call %d" % (len(hist) - 1))
+
+    for _ in range(6):
+        run(1, 2, 2, 0.6)            # calls 2.. carry
+    run(0, 2, 2, 0.6)                # a zero-cycle call in between keeps what was carried
+    run(1, 2, 2, 0.6)
+    run(3, 2, 2, 0.6)                # a longer continuation
+    run(1, 1, 2, 0.6)                # other sweep counts: the carried leg is dropped
+    for _ in range(4):
+        run(2, 1, 2, 0.6)
+    run(1, 1, 2, 0.7)                # other omega
+    for _ in range(4):
+        run(1, 3, 1, 0.7)
+    plan.set(mg.to_device(f), mg.to_device(ref_v))   # data replaced (same values): carried leg dropped
+    for _ in range(4):
+        run(1, 3, 1, 0.7)
+    for _ in range(4):
+        run(1, 1, 0, 0.6)            # no post-smoothing: the end-of-cycle iterate is stage 0 of the closing launch
+    for _ in range(3):
+        run(1, 0, 2, 0.6)            # no pre-smoothing: nothing to carry
+    for _ in range(3):
+        run(1, 2, 3, 0.6)            # more than four sweeps: not the lean schedule
+    plan.close()

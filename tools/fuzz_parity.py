@@ -1,6 +1,10 @@
-"""Randomised parity sweep (not part of the test suite): random hierarchy shapes, sweep
-counts, omega, schedules, boundary data and cycle counts against the CPU oracle, bit for bit.
-   python tools/fuzz_parity.py [seconds] [seed] [largest size]"""
+"""Randomised parity sweep: random hierarchy shapes, sweep counts, omega, schedules, boundary
+data and cycle counts against the CPU oracle, bit for bit.  The test suite runs a small budget
+of the partitioned-plan cases (tests/test_gpu_mplan.py); long sweeps are run by hand.
+   python tools/fuzz_parity.py [seconds] [seed] [largest size]
+   FUZZ_MODES=3,4  only these kinds of case (0 full multigrid, 1 slab driver, 2 exact coarsest
+                   solve, 3/4 partitioned plan, others: the single plan)
+   FUZZ_CASES=200  stop after this many cases"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +17,9 @@ MAXM = int(sys.argv[3]) if len(sys.argv) > 3 else 1800
 t_end = time.time() + budget
 t_say = time.time() + 30
 n = 0
-while time.time() < t_end:
+only = [int(x) for x in os.environ["FUZZ_MODES"].split(",")] if os.environ.get("FUZZ_MODES") else None
+most = int(os.environ.get("FUZZ_CASES", "0"))
+while time.time() < t_end and not (most and n >= most):
     if time.time() > t_say:
         print("... %d cases so far" % n, flush=True)
         t_say = time.time() + 30
@@ -35,6 +41,8 @@ while time.time() < t_end:
     v0 = np.asfortranarray(rng.standard_normal((M, M)) * float(rng.choice([0.0, 1.0])))
     dx = float(rng.choice([1.0, 1.0 / (M - 1), 0.37]))
     mode = int(rng.integers(0, 10))
+    if only is not None:
+        mode = int(rng.choice(only))
     if os.environ.get("FUZZ_LOG"):  # one line per case, so that a hang names its case
         with open(os.environ["FUZZ_LOG"], "a") as fh:
             fh.write("case %d: %r\n" % (n, dict(M=M, coarsest=coarsest, nd=nd, nu=nu, omega=omega, Nv=Nv, sched=sched,
