@@ -287,7 +287,12 @@ int mgx_residual_norm(const double *v_dev, const double *f_dev, int m, double dx
  * double), stream-ordered on `stream`.  Its partial results live in a fixed 64 KiB device
  * array inside the library (one per GPU, held until the process ends), which bounds the grid
  * it accepts: m <= 65537, larger sizes are rejected with MGX_ERR_ARG.  All calls on one GPU
- * share that array: calls that overlap on one GPU (different streams or threads) race. */
+ * share that array: calls that overlap on one GPU (different streams or threads) race, and so
+ * do replays of a captured graph on two streams.  The first use on a device looks up the
+ * array's address (hipGetSymbolAddress, which may load the library's device code): that must
+ * not happen under stream capture.  mgx_plan_create() and mgx_mplan_create() do the look-up
+ * for the device they run on; a caller that creates no plan makes one call outside capture
+ * first. */
 int mgx_residual_norm_noalloc(const double *v_dev, const double *f_dev, int m, double dx, double *norm_dev,
                               void *stream);
 

@@ -799,6 +799,7 @@ static int plan_create_on_device(mgx_plan **out, int m, double dx, int coarsest,
             return fail(MGX_ERR_HIP, "hipGetDevice: %s (is a GPU visible?)", hipGetErrorString(e));
         }
     }
+    noalloc_prepare_device();  // (see mgx_residual_norm_noalloc: its first call may come under stream capture)
     p->coarsest = coarsest;
     p->depth = depth;
     p->use_tail = getenv("MGX_NO_TAIL") ? 0 : 1;

@@ -101,6 +101,10 @@ hipError_t launch_norminf(const double *a, size_t len, unsigned long long *slot,
 hipError_t launch_residual_norm(const double *u, const double *f, int m, int jlo, int jhi, const SweepCoef &c,
                                 unsigned long long *slot, hipStream_t s);
 
+// resolves, for the current device, the address of the fixed device array that
+// mgx_residual_norm_noalloc() keeps its partial results in (mgx_noalloc.hip)
+void noalloc_prepare_device();
+
 // ---- ordinary (pageable) host arrays <-> device, several threads through pinned staging
 // buffers (mgx_hostio.hip).  Synchronous; work already enqueued on `order` comes first.
 hipError_t host_to_device(double *dst_dev, const double *src_host, size_t count, hipStream_t order);

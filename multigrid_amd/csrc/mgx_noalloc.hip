@@ -51,6 +51,19 @@ hipError_t scratch_on_current_device(double **out)
     return hipSuccess;
 }
 
+} // namespace
+
+// Look the array up for the current device now (mgx_plan_create and mgx_mplan_create call this),
+// so that a later mgx_residual_norm_noalloc() on this device, possibly under stream capture,
+// finds the address cached and makes no runtime call but its two launches.
+void mgx::noalloc_prepare_device()
+{
+    double *p = nullptr;
+    if (scratch_on_current_device(&p) != hipSuccess) (void)hipGetLastError();
+}
+
+namespace {
+
 // Workgroup (bx, by) walks columns 1 + by*NA_BY + ty, stride gridDim.y*NA_BY, of rows
 // 1 + bx*64 + tx, and writes the maximum |residual| it saw to partials[bx + by*gridDim.x].
 // Boundary entries of the residual are +0.0 (main.cpp:267), so accumulators start at +0.0.

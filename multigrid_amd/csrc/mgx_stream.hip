@@ -535,7 +535,11 @@ struct LaunchShape {
     size_t lds = 0;
 };
 
-// Plain shape.  Chunk length: long enough to amortise the pipeline warm-up on a large
+// Plain shape.  (For the tall slabs of the coarser levels of a partitioned run -- 8193 x 1100,
+// 4097 x 540, the iterate known to be zero -- chunks two, four and eight times as long as this
+// rule's 16 / 8 columns were measured as tuner candidates and lost, 64 -> 68 -> 87 -> 127 us per
+// three launches: those launches want workgroups, not fewer halo columns.)
+// Chunk length: long enough to amortise the pipeline warm-up on a large
 // level (256 columns: 4 % of re-read), short enough that a small level still spreads
 // over the chip (down to 4 columns: a small level is latency-bound, so a shorter march
 // beats less redundant work).

@@ -137,3 +137,28 @@ def test_hostile_dimensions_in_the_file_are_refused(tmp_path):
         (tmp_path / "Input.mat").write_bytes(body)
         rc, out = run(["-v", "1"], tmp_path)
         assert rc == 1 and ("do not fit the file" in out or "no variable f" in out), (mrows, ncols, out)
+
+
+@pytest.mark.gpu
+def test_the_command_line_mgtester_runs(O, tmp_path):
+    """MGTester.m:150-153 shells out to `build/Release/multigrid -v 50 -b Nb -a Na -o omega` from
+    the directory that holds Input.mat.  `make mgtester` puts the driver at that path; the
+    tester's command line, character for character, gives the oracle's Output.mat."""
+    from multigrid_amd import rhs
+    exe = os.path.join(ROOT, "build", "Release", "multigrid")
+    if not os.path.exists(exe):
+        pytest.skip("build/Release/multigrid not built (make -C multigrid_amd/csrc mgtester)")
+    (tmp_path / "build" / "Release").mkdir(parents=True)
+    os.symlink(exe, tmp_path / "build" / "Release" / "multigrid")
+    M = 129
+    h = 1.0 / (M - 1)
+    f = rhs.smooth_np(M)                                          # MGTester.m:136-141, libm-free variant
+    mat4.write(tmp_path / "Input.mat", [("Seq_f", np.zeros((1, 2))), ("f", f), ("f_loc", np.array([[0.0, 0.0, h, h]]))])
+    cmd = "build/Release/multigrid -v 50 -b 3 -a 3 -o 0.8"        # runMG(3, 3, 0.8)
+    p = subprocess.run(cmd, shell=True, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout
+    got = mat4.read(tmp_path / "Output.mat")
+    sol, rn, _ = O.multigrid(f, np.zeros((M, M), order="F"), h, 50, 3, 3, 0.8, 2)
+    assert_bits(got["ResNorms"].ravel(), rn, "ResNorms")
+    assert_bits(got["Sol"], sol, "Sol")
+    assert got["Times"].shape[0] == 51

@@ -344,7 +344,7 @@ def test_45057_over_eight_slabs_like_the_weak_scaling_run(mg):
     assert differ == 0
     a, b, differ, rel, _, _ = _plan_and_slabs_agree(mg, 45057, 11, 8, 6, exact=True)
     assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * a[0]) and rel <= 1e-9
-    assert b[6] < 1e-3 * b[0]
+    assert b[6] < 5e-3 * b[0]      # six cycles at the usual 0.35 per cycle
 
 
 def test_full_multigrid_32769_over_four_slabs(mg):
