@@ -6,8 +6,8 @@ levels and over the launch shapes the tuner tries before the timed region).
 Which launches those are: a kernel that reads the iterate (template argument ZERO_IN = false)
 runs on level 0 only, in a launch shape the tuner measures first; the shape in use afterwards is
 the grid of the kernel's LAST dispatch, so only launches of that grid count.  A kernel with
-ZERO_IN = true runs on every coarser level in one fixed shape per level; its largest grid is the
-finest level.
+ZERO_IN = true runs on every coarser level in one fixed shape per level; the grid whose launches
+take longest is the finest level.
 
   python profiles/summarize.py gpurun_out/<dir>/<host>/<pid>_kernel_trace.csv > profiles/<name>.txt
 """
@@ -34,7 +34,13 @@ def main(path):
     tot = sum(d for v in by.values() for (_, d, *_r) in v)
     for name, v in sorted(by.items(), key=lambda kv: -sum(d for (_, d, *_r) in kv[1])):
         tuned = "k_stream" in name and ", false, " in name
-        gsel = v[-1][0] if tuned else max(g for (g, *_r) in v)
+        if tuned:
+            gsel = v[-1][0]
+        else:  # the finest level is the grid whose launches take longest (chunk lengths differ per level)
+            per = collections.defaultdict(list)
+            for (g, d, *_r) in v:
+                per[g].append(d)
+            gsel = max(per, key=lambda g: sum(per[g]) / len(per[g]))
         fine = [d for (g, d, *_r) in v if g == gsel]
         _, _, vg, sg, lds, scr = v[0]
         short = name if len(name) <= 100 else name[:97] + "..."
