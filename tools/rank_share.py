@@ -79,8 +79,10 @@ def main():
     for k, (cnt, ms) in sorted(prof.items()):
         p = pts.get(k, 0) / max(cnt, 1)
         us = ms / cnt * 1e3
-        res["level0"][k] = {"launches": cnt, "avg_us": us, "points": p,
-                            "frac_of_peak_at_28B": 28.0 * p / (us * 1e-6) / 8e12 if us > 0 else None}
+        # bytes a launch must move per point: up+down (and its edge band) 28, down and up 26, norm 16
+        bpp = {"k_stream:norm": 16.0, "k_stream:down": 26.0, "k_stream:up": 26.0}.get(k, 28.0)
+        res["level0"][k] = {"launches": cnt, "avg_us": us, "points": p, "bytes_per_point": bpp,
+                            "frac_of_peak": bpp * p / (us * 1e-6) / 8e12 if us > 0 else None}
         l0 += ms
     res["level0_ms_per_cycle"] = l0 / args.cycles
     res["rest_ms_per_cycle"] = res["device_ms_per_cycle"] - res["level0_ms_per_cycle"]
