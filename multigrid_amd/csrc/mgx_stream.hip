@@ -289,11 +289,10 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
 
     double nacc = 0.0;  // NORM: running max |r| (boundary residuals are +0.0)
 
-    // One column step; ODD is the parity of the global column index of jin, SLOT the place
-    // of column jin in the load-ahead queues (the step number modulo PF).
-    auto step = [&](const int jin, auto odd_tag, auto slot_tag) {
+    // One column step on column jin of the input (u0, f1: the iterate of column jin and the
+    // right-hand side of column jin-1); ODD is the parity of the global column index of jin.
+    auto step_core = [&](const int jin, auto odd_tag, P2 u0, const P2 f1) {
         constexpr bool ODD = decltype(odd_tag)::value;
-        constexpr int SLOT = decltype(slot_tag)::value;
 
         // P(coarse) added to column jp (parity ODDP) of stage PA
         auto add_correction = [&](P2 &x, const int jp, auto oddp_tag) {
@@ -340,14 +339,6 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
             if (colok && owna) nacc = (nacc < xa) ? xa : nacc;
             if (colok && ownb) nacc = (nacc < xb) ? xb : nacc;
         };
-
-        // ---- take column jin from its place in the load-ahead queues and refill that place:
-        // a queue that shifted would move registers that loads are still in flight to, and the
-        // moves at the end of a trip would wait for every one of them
-        P2 u0 = Pu[SLOT];
-        const P2 f1 = Pf[SLOT];
-        if (!ZERO_IN) Pu[SLOT] = load_col(pua, pub, jin + PF);
-        Pf[SLOT] = load_col(pfa, pfb, jin - 1 + PF, true);
 
         // ---- stage 0 ---------------------------------------------------------
         if (PA == 0) add_correction(u0, jin, std::integral_constant<bool, ODD>{});
@@ -428,9 +419,22 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
             }
         }
     };
+    // The same with column jin taken from its place in the load-ahead queues (SLOT: the step
+    // number modulo PF) and that place refilled at once.
+    auto step = [&](const int jin, auto odd_tag, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        const P2 u0 = Pu[SLOT];
+        const P2 f1 = Pf[SLOT];
+        if (!ZERO_IN) Pu[SLOT] = load_col(pua, pub, jin + PF);
+        Pf[SLOT] = load_col(pfa, pfb, jin - 1 + PF, true);
+        step_core(jin, odd_tag, u0, f1);
+    };
 
 #ifndef MGX_LOCKSTEP
 #define MGX_LOCKSTEP 8
+#endif
+#ifndef MGX_TRIP
+#define MGX_TRIP 0  // 1: a trip of PF columns whose loads are all issued at the start of the trip before
 #endif
 #ifndef MGX_UNROLL6
 // Measured on the level-0 launch: the six-column trip executes 20 % fewer vector instructions and
@@ -444,7 +448,44 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
     // 8: 1.487, 4: 1.487, 2: 1.497).  All waves of a workgroup march the same chunk, hence the
     // same trip count; a wave that has exited is not waited for.
     using std::integral_constant;
-    if ((MGX_UNROLL6 && !EDGE) || PF != 2) {
+    if constexpr (MGX_TRIP != 0) {
+        // Trips of PF columns: the queues hold the whole trip; at the start of a trip they are
+        // emptied into the trip's own registers and refilled with the NEXT trip's columns, every
+        // load at once, so that each has the whole trip to arrive (a column-by-column refill gives
+        // the last one a single step).  The last trip may march up to PF-2 columns past jlast:
+        // loads are clamped, nothing past jb is stored or merged.
+        static_assert(PF % 2 == 0 && PF <= 8, "trips are 2, 4, 6 or 8 columns");
+        for (int jin = jstart; jin <= jlast; jin += PF) {
+#if MGX_LOCKSTEP > 0
+            if (PF >= MGX_LOCKSTEP || ((jin - jstart) & (MGX_LOCKSTEP - 1)) == 0) __builtin_amdgcn_s_barrier();
+#endif
+            P2 cu[PF], cf[PF];
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                cu[k] = Pu[k];
+                cf[k] = Pf[k];
+            }
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                if (!ZERO_IN) Pu[k] = load_col(pua, pub, jin + PF + k);
+                Pf[k] = load_col(pfa, pfb, jin - 1 + PF + k, true);
+            }
+            step_core(jin, std::false_type{}, cu[0], cf[0]);
+            step_core(jin + 1, std::true_type{}, cu[1], cf[1]);
+            if constexpr (PF >= 4) {
+                step_core(jin + 2, std::false_type{}, cu[2], cf[2]);
+                step_core(jin + 3, std::true_type{}, cu[3], cf[3]);
+            }
+            if constexpr (PF >= 6) {
+                step_core(jin + 4, std::false_type{}, cu[4], cf[4]);
+                step_core(jin + 5, std::true_type{}, cu[5], cf[5]);
+            }
+            if constexpr (PF >= 8) {
+                step_core(jin + 6, std::false_type{}, cu[6], cf[6]);
+                step_core(jin + 7, std::true_type{}, cu[7], cf[7]);
+            }
+        }
+    } else if constexpr ((MGX_UNROLL6 && !EDGE) || PF != 2) {
         // Six columns per trip: the register queues rotate with periods 2 (load-ahead, column
         // parity), 3 (the three newest columns of a stage, the residual columns, the coarse
         // columns every other step) and NS+1, so after six steps every value is back in the

@@ -69,3 +69,27 @@ def test_rhs_generators_numpy():
     t = rhs.random_torch(17, device="cpu").numpy()
     assert np.array_equal(r, t)
     assert np.array_equal(f, rhs.smooth_torch(17, device="cpu").numpy())
+
+
+def test_slab_op_accepts_the_struct_without_the_second_range():
+    """mgx_slab_op grew a second column range (jlo2, jhi2) at its end; a caller built against the
+    older struct passes the smaller struct_size and must get past the size check (the next check,
+    a null input, answers instead); any other size is refused.  No GPU call is made."""
+    lib = _lib()
+    L = lib.load()
+    op = lib.mgx_slab_op()
+    full = ctypes.sizeof(lib.mgx_slab_op)
+    old = lib.mgx_slab_op.jlo2.offset
+    assert full - old == 8
+    for size, expect in ((full, b"null input"), (old, b"null input"), (old - 4, b"struct_size"), (full + 8, b"struct_size")):
+        op.struct_size = size
+        op.m, op.ld, op.ncols = 9, 9, 9
+        op.nsweeps, op.pro_stage, op.norm_stage, op.store = 1, -1, -1, 1
+        assert L.mgx_slab_launch(ctypes.byref(op), None) == -1
+        assert expect in L.mgx_last_error(), (size, L.mgx_last_error())
+
+
+def test_tune_report_is_empty_before_anything_ran():
+    lib = _lib()
+    assert lib.tune_report() == [] or all("k_stream<" in l for l in lib.tune_report())
+    assert lib.load().mgx_tune_report(None, 0) >= 1

@@ -67,3 +67,64 @@ def test_fused_up_nonzero_coarse_boundary(mg, O):
     O.lib().mgo_plus_equals(v_ref.ctypes.data_as(O._dp), fine.ctypes.data_as(O._dp), v_ref.size)
     v_ref = O.relax(v_ref, f, dx, 2, 0.6)
     assert_bits(mg.to_numpy(p.v), v_ref, "nonzero coarse boundary")
+
+
+@pytest.mark.gpu
+def test_two_column_ranges_in_one_launch(O):
+    """mgx_slab_op.jlo2/jhi2: one launch that produces two bands of columns (the columns next to
+    both neighbours of a slab, launched ahead of the interior) equals two launches of one band each,
+    and together with the interior launch the whole-range launch, bit for bit -- for every kind of
+    leg that a partitioned level-0 launch runs, with the norm merged by both."""
+    import ctypes
+    import torch
+    from multigrid_amd import _lib
+    L = _lib.load()
+    m, ncols = 2049, 300
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda")
+    f = torch.from_numpy(rng.standard_normal((ncols, m))).to(dev)
+    vin = torch.from_numpy(rng.standard_normal((ncols, m))).to(dev)
+    mc, nccols = (m - 1) // 2 + 1, 160
+    cv = torch.from_numpy(rng.standard_normal((nccols, mc))).to(dev)
+    gf0, gc0 = 4000, 1996           # local column 0 is global fine column 4000; coarse column 1996 <-> fine 3992
+    jlo, jhi, B = 12, 288, 40
+
+    def launch(ns, pa, nm, res, store, ranges):
+        vout = torch.zeros_like(vin)
+        cf = torch.zeros((nccols, mc), dtype=torch.float64, device=dev)
+        slot = torch.zeros(1, dtype=torch.int64, device=dev)
+        for rg in ranges:
+            o = _lib.mgx_slab_op()
+            o.struct_size = ctypes.sizeof(_lib.mgx_slab_op)
+            o.nsweeps, o.pro_stage, o.norm_stage, o.restrict_out, o.zero_in, o.store = ns, pa, nm, res, 0, store
+            o.v_in, o.v_out, o.f = vin.data_ptr(), vout.data_ptr(), f.data_ptr()
+            o.coarse_v, o.coarse_f, o.norm_slot = cv.data_ptr(), cf.data_ptr(), slot.data_ptr()
+            o.m, o.ld, o.ncols, o.mc, o.ldc, o.nccols = m, m, ncols, mc, mc, nccols
+            o.jlo, o.jhi = rg[0]
+            if len(rg) > 1:
+                o.jlo2, o.jhi2 = rg[1]
+            o.jfix_lo = o.jfix_hi = -1
+            o.gf0, o.gc0, o.dx, o.omega = gf0, gc0, 1.0 / 4096, 0.6
+            _lib.check(L.mgx_slab_launch(ctypes.byref(o), None))
+        torch.cuda.synchronize()
+        return vout.cpu().numpy(), cf.cpu().numpy(), int(slot.item())
+
+    lo, hi, mid = (jlo, jlo + B), (jhi - B, jhi), (jlo + B, jhi - B)
+    for (ns, pa, nm, res, store) in ((4, 0, 2, 1, 1), (2, -1, -1, 1, 1), (2, 0, 2, 0, 1), (0, -1, 0, 0, 0), (3, 0, 1, 1, 1)):
+        whole = launch(ns, pa, nm, res, store, [((jlo, jhi),)])
+        split = launch(ns, pa, nm, res, store, [(lo, hi), (mid,)])        # two bands in one launch + the interior
+        three = launch(ns, pa, nm, res, store, [(lo,), (hi,), (mid,)])    # three launches
+        only2 = launch(ns, pa, nm, res, store, [((jlo, jlo), hi), (lo,), (mid,)])   # an empty first range
+        for other, what in ((split, "two ranges + interior"), (three, "three launches"), (only2, "empty first range")):
+            for a, b, name in zip(whole, other, ("v_out", "coarse_f", "norm")):
+                assert np.array_equal(np.asarray(a).view(np.uint64) if name != "norm" else a,
+                                      np.asarray(b).view(np.uint64) if name != "norm" else b), (ns, pa, nm, res, what, name)
+    # a second range that overlaps or precedes the first is refused
+    o = _lib.mgx_slab_op()
+    o.struct_size = ctypes.sizeof(_lib.mgx_slab_op)
+    o.nsweeps, o.pro_stage, o.norm_stage, o.restrict_out, o.store = 2, -1, -1, 0, 1
+    o.v_in, o.v_out, o.f = vin.data_ptr(), torch.zeros_like(vin).data_ptr(), f.data_ptr()
+    o.m, o.ld, o.ncols, o.jlo, o.jhi, o.jlo2, o.jhi2 = m, m, ncols, 50, 100, 90, 120
+    o.jfix_lo = o.jfix_hi = -1
+    o.dx, o.omega = 1.0, 0.6
+    assert L.mgx_slab_launch(ctypes.byref(o), None) == -1 and b"second range" in L.mgx_last_error()
