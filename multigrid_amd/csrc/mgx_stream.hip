@@ -434,7 +434,11 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
 #define MGX_LOCKSTEP 8
 #endif
 #ifndef MGX_TRIP
-#define MGX_TRIP 0  // 1: a trip of PF columns whose loads are all issued at the start of the trip before
+// 1: trips of PF columns with the next trip's loads all issued at the start of the trip.  Measured
+// (16385^2 cycle / level-0 launch / one rank's cycle of eight): column-by-column refill 2.100 ms /
+// 1.471 ms / 0.418 ms; trips of 2: 2.14-2.25 / 1.50-1.62 / 0.418; of 4: 2.16 / 1.51 / 0.433; of 6 and 8:
+// 2.23 / 1.56 / 0.444-0.456.  Longer queues do not pay, not even on the small latency-bound levels: off.
+#define MGX_TRIP 0
 #endif
 #ifndef MGX_UNROLL6
 // Measured on the level-0 launch: the six-column trip executes 20 % fewer vector instructions and
