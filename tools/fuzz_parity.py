@@ -3,7 +3,7 @@ data and cycle counts against the CPU oracle, bit for bit.  The test suite runs 
 of the partitioned-plan cases (tests/test_gpu_mplan.py); long sweeps are run by hand.
    python tools/fuzz_parity.py [seconds] [seed] [largest size]
    FUZZ_MODES=3,4  only these kinds of case (0 full multigrid, 1 slab driver, 2 exact coarsest
-                   solve, 3/4 partitioned plan, others: the single plan)
+                   solve, 3/4 partitioned plan, 5 a series of short calls on one plan, others: one call)
    FUZZ_CASES=200  stop after this many cases"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -132,6 +132,44 @@ while time.time() < t_end and not (most and n >= most):
                 np.array_equal(v.view(np.uint64), sol.view(np.uint64))):
             print("MPLAN MISMATCH", dict(M=M, coarsest=coarsest, nd=nd, nu=nu, omega=omega, Nv=Nv, k1=k1, pj=pj, dx=dx,
                                          tail_m=tail_m, R=R, ndist=ndist))
+            sys.exit(1)
+        continue
+    if mode == 5 and not pj:  # one plan driven by a series of short calls (what a call leaves for the next one)
+        try:
+            O.multigrid(f, v0, dx, 0, nd, nu, omega, coarsest)
+        except ValueError:
+            continue
+        try:
+            plan = mg.Plan(M, dx, coarsest, schedule=sched)
+        except mg.MgxError:
+            continue
+        plan.set(mg.to_device(f), mg.to_device(v0))
+        ref_v, ok, log = v0, True, []
+        cur = (nd, nu, omega)
+        for call in range(int(rng.integers(3, 12))):
+            r = rng.random()
+            if r < 0.15:
+                cur = (int(rng.integers(0, 5)), int(rng.integers(0, 4)), float(rng.choice([0.6, 0.8])))
+            ncyc = int(rng.choice([0, 1, 1, 1, 2, 3]))
+            out = plan.cycles(ncyc, cur[0], cur[1], cur[2])
+            sol, rn, _ = O.multigrid(f, ref_v, dx, ncyc, cur[0], cur[1], cur[2], coarsest)
+            ref_v = sol
+            log.append((ncyc,) + cur)
+            ok = ok and np.array_equal(out.ResidualNorms.view(np.uint64), rn.view(np.uint64))
+            r = rng.random()
+            if r < 0.3:
+                ok = ok and np.array_equal(mg.to_numpy(plan.get()).view(np.uint64), ref_v.view(np.uint64))
+                log.append("get")
+            elif r < 0.4:
+                plan.set(mg.to_device(f), mg.to_device(ref_v))
+                log.append("set")
+            if not ok:
+                break
+        ok = ok and np.array_equal(mg.to_numpy(plan.get()).view(np.uint64), ref_v.view(np.uint64))
+        plan.close()
+        n += 1
+        if not ok:
+            print("SERIES MISMATCH", dict(M=M, coarsest=coarsest, sched=sched, dx=dx), log)
             sys.exit(1)
         continue
     if mode == 2 and not pj:  # the exact coarsest solve (an extension): agreement to rounding, not bitwise

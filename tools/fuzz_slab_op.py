@@ -64,6 +64,13 @@ while time.time() < t_end:
     cv = rng.standard_normal((nccols, mc))
     cf0 = rng.standard_normal((nccols, mc))
     dx, omega = float(rng.choice([1.0, 0.01, 0.37])), float(rng.choice([0.6, 0.8, 1.0]))
+    # every third case produces TWO column ranges in the one launch (the bands next to both
+    # neighbours of a slab): [jlo, a) and [b, jhi) with a gap between them
+    j1, j2lo, j2hi = jhi, 0, 0
+    if own >= 4 and rng.integers(0, 3) == 0:
+        a = jlo + int(rng.integers(0, own // 2 + 1))        # the first range may be empty
+        b = a + int(rng.integers(1, jhi - a))
+        j1, j2lo, j2hi = a, b, jhi
     outs = []
     for be in (hip, ref):
         conv = be.from_numpy
@@ -73,8 +80,8 @@ while time.time() < t_end:
                          v_in=None if zin else conv(vin), v_out=vo if st else None, f=conv(f),
                          coarse_v=conv(cv) if pa >= 0 else None, coarse_f=cf if res else None,
                          norm_slot=be.slot_ptr(slots, 0) if nm >= 0 else None, m=m, ncols=ncols, mc=mc, nccols=nccols,
-                         jlo=jlo, jhi=jhi, jfix_lo=0 if left else -1, jfix_hi=ncols - 1 if right else -1, gf0=gf0, gc0=gc0,
-                         dx=dx, omega=omega)
+                         jlo=jlo, jhi=j1, jlo2=j2lo, jhi2=j2hi, jfix_lo=0 if left else -1,
+                         jfix_hi=ncols - 1 if right else -1, gf0=gf0, gc0=gc0, dx=dx, omega=omega)
         be.launch(op)
         be.synchronize()
         outs.append((be.to_numpy(vo), be.to_numpy(cf), be.decode_slots(slots)[0]))
@@ -83,7 +90,7 @@ while time.time() < t_end:
         and (na == nb or (nm < 0))
     n += 1
     if not same:
-        print("MISMATCH", dict(leg=(ns, pa, nm, res, zin, st), m=m, ncols=ncols, jlo=jlo, jhi=jhi, left=left, right=right, gf0=gf0,
+        print("MISMATCH", dict(leg=(ns, pa, nm, res, zin, st), m=m, ncols=ncols, jlo=jlo, jhi=j1, jlo2=j2lo, jhi2=j2hi, left=left, right=right, gf0=gf0,
                                gc0=gc0, nccols=nccols, dx=dx, omega=omega))
         print(" v differs at", np.argwhere(va != vb)[:6].tolist(), " coarse f differs at", np.argwhere(ca != cb)[:6].tolist(),
               " norms", na, nb)
