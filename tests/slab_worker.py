@@ -62,12 +62,24 @@ def main():
     v0[0, 3] = v0[5, 0] = v0[-1, -1] = v0[-1, 7] = v0[M // 2, -1] = -0.0     # main.cpp:341 turns these into +0.0
 
     S = slab.SlabSolver(M, dx, coarsest, backend=be, tail_m=tail_m, halo=8)
+    two_range = [0]
+    if os.environ.get("MGX_WORKER_COUNT_TWO_RANGE") == "1":  # count the launches that produce two column ranges
+        plain_launch = be.launch
+
+        def counting_launch(op):
+            if op.jhi2 and op.jhi2 > op.jlo2:
+                two_range[0] += 1
+            plain_launch(op)
+
+        be.launch = counting_launch
     S.set_problem(f, v0)
     out = S.fmg(Nv, nd, nu, omega) if fmg else S.cycles(Nv, nd, nu, omega, pureJacobi=bool(pure))
     sol = S.gather_solution()
     S.close()
 
     ok = True
+    if os.environ.get("MGX_WORKER_COUNT_TWO_RANGE") == "1":
+        print("slab_worker: rank %d two_range_launches=%d" % (rank, two_range[0]), flush=True)
     if rank == 0:
         if fmg:
             ref_sol, ref_rn = O.fmg(f, v0, dx, Nv, nd, nu, omega, coarsest, coarse_exact=exact)

@@ -55,3 +55,25 @@ def test_a_failing_rank_ends_the_launch_with_its_status():
     assert r.returncode != 0
     assert r.stdout.decode().strip() == ""
     assert b"rank 0 ended with status" in r.stderr or b"rank 1 ended with status" in r.stderr
+
+
+@pytest.mark.gpu
+def test_under_torch_distributed_run():
+    """The way a multi-GPU scaling run is launched: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`: the script
+    takes the ranks it is given (it starts none of its own) and rank 0 prints the one line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MGX_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--size", "2049", "--steps", "3", "--warmup", "1"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["comm"]["rccl_world"] == 2 and d["comm"]["launcher"] == "torch.distributed.run"

@@ -173,3 +173,15 @@ def test_ownership_is_nested_and_covers_every_level(O):
             assert fine[g + 1] - fine[g] >= 8
         b = fine
     S.close()
+
+
+def test_a_middle_rank_launches_both_edge_bands_at_once(O):
+    """Three ranks, 513^2, one distributed level: the middle rank has two neighbours and is wide
+    enough to split its level-0 launches, so the columns next to BOTH neighbours go out as one
+    launch of two column ranges (SlabOp.jlo2/jhi2) ahead of the interior.  Bit-identical to the
+    oracle like every other decomposition; the worker reports how many such launches it made."""
+    codes, outs = run_ranks(3, ["numpy", 513, 3, 2, 2, 0.6, 257, 0], extra_env={"MGX_WORKER_COUNT_TWO_RANGE": "1"})
+    assert codes == [0] * 3, "\n".join(outs)
+    assert "resnorms_equal=True sol_equal=True" in outs[0]
+    assert "two_range_launches=" in outs[1] and "two_range_launches=0" not in outs[1], outs[1]
+    assert "two_range_launches=0" in outs[0]          # a boundary rank has one neighbour: one band
