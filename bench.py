@@ -401,9 +401,18 @@ def main():
         for (d, m_d, n, ms) in rows:
             comp = 28.0 * float(m_d) * m_d if d < 4 else None
             us = ms * 1e3 / nlev
-            levels.append({"level": d, "m": m_d, "launches_per_cycle": n / float(nlev), "us_per_cycle": round(us, 2),
-                           "compulsory_bytes": comp,
-                           "frac": round(comp / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if comp else None})
+            rec = {"level": d, "m": m_d, "launches_per_cycle": n / float(nlev), "us_per_cycle": round(us, 2),
+                   "compulsory_bytes": comp}
+            if comp and d == 0:
+                # every level-0 launch moves the level once (up+down 28 B/point; the call's opening
+                # down and closing up launch 26): judged per launch, not per cycle of this short run
+                rec["us_per_launch"] = round(ms * 1e3 / n, 2)
+                rec["frac"] = round(comp / (ms * 1e-3 / n) / 1e9 / HBM_PEAK_GBS, 4)
+            elif comp:
+                rec["frac"] = round(comp / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)  # down + up leg together: 10 + 18 B/point
+            else:
+                rec["frac"] = None
+            levels.append(rec)
 
     if rank == 0:
         n0 = float(M) * M
@@ -464,7 +473,7 @@ def main():
             line["levels"] = levels
             line["levels_note"] = ("a separate run of 5 cycles with every launch between events (adds a few us per "
                                    "small launch); a launch over several small levels is booked on its finest level; "
-                                   "the level-0 figure includes the opening down and closing up launch of the call")
+                                   "level 0: 6 launches in these 5 cycles (the call's opening down and closing up launch), frac per launch")
         if grouped or args.slab or args.mplan:
             main = [i["level0_avg_ms"].get(kname) for i in infos if i and i["level0_avg_ms"].get(kname)] if roof else []
             line["comm"] = {
