@@ -211,6 +211,11 @@ def launch_ranks(n, out_fd):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else None))
+    # rank 0's stdout is read while it runs (a line longer than the pipe's buffer must not block it)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     t0 = time.time()
     worst, failed_at = 0, None
     live = set(range(n))
@@ -238,9 +243,10 @@ def launch_ranks(n, out_fd):
                 sys.stderr.write("bench.py: ranks still running after %.0f s were ended\n" % limit)
             break
         time.sleep(0.05)
-    text = procs[0].stdout.read()
     for p in procs:
         p.wait()
+    reader.join(timeout=30)
+    text = b"".join(chunks)
     lines = [l for l in text.decode(errors="replace").splitlines() if l.startswith("{")]
     if lines:
         os.write(out_fd, (lines[-1] + "\n").encode())

@@ -143,7 +143,9 @@ size_t mgx_plan_bytes(const mgx_plan *plan); /* HBM held by the plan */
  * and forgets what it may have computed ahead from the old data (see
  * mgx_plan_cycles).  mgx_plan_v_dev() names the buffer that holds the current
  * iterate: the plan's iterate buffers trade places inside mgx_plan_cycles()
- * (no copy of the grid), so ask again after it returns.  mgx_plan_f_dev() never
+ * (no copy of the grid), so ask again after it returns.  After a series of short calls the
+ * iterate may not be in memory yet (see mgx_plan_cycles): mgx_plan_v_dev() then enqueues the one
+ * launch that produces it on the plan's stream before it answers (NULL if that launch fails).  mgx_plan_f_dev() never
  * changes, and mgx_plan_vcycle_async() leaves mgx_plan_v_dev() as it is. */
 double *mgx_plan_f_dev(mgx_plan *plan);
 double *mgx_plan_v_dev(mgx_plan *plan);

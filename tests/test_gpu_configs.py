@@ -388,4 +388,4 @@ def test_16385_single_cycle_calls_cost_what_one_long_call_costs(mg):
     assert_bits(got, one.ResidualNorms, "ResNorms, 24 calls of one cycle")
     assert all(h[0] == g[-1] for h, g in zip(hist[1:], hist[:-1]))
     assert fp_one == fp_many
-    assert t_many < 1.12 * t_one
+    assert t_many < 1.30 * t_one       # measured x1.08; two level-0 launches per cycle would be x1.7
