@@ -7,8 +7,11 @@ One "step" is one V(2,2) cycle (omega 0.6, coarsest 2) of the 2D Poisson solver
 on an M x M fp64 grid, synthetic random right-hand side generated on the GPU,
 zero initial guess, everything resident in HBM before the timed region.  The
 metric is fine-grid DOF/s per V-cycle = M^2 * K / seconds.  For N > 1 the same
-M x M problem is split into j-slabs (strong scaling) and the script is launched
-once per GPU by torch.distributed.run.
+M x M problem is split into j-slabs (strong scaling), one rank per GPU: started
+as `python bench.py --gpus N` the script starts its own N ranks as child
+processes (before it imports torch or touches a GPU); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it takes
+the ranks it is given.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the kernel with the largest
 share of the timed region (HIP events around every fine-level launch, on the
