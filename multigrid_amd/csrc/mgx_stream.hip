@@ -835,16 +835,10 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
         // A narrow band of a tall level (the columns next to a neighbour, launched ahead of the
         // rest so that the exchange can start): the plain rule would cut it into chunks of 4
         // columns, each marching its 11 halo columns too.  Longer chunks move fewer bytes, fewer
-        // chunks march longer: measured.
+        // chunks march longer: measured (two, four and eight strips per workgroup give the same 40 us
+        // at their best chunk length: four it is).
         const int width = std::max(A.jhi - A.jlo, A.jhi2 - A.jlo2);
-        static const int edge_cj = env_int("MGX_EDGE_CJ", 0);  // experiment knob: a fixed chunk length, unmeasured
-        if (edge_cj > 0) {
-            cands[0].nwv = 4;
-            cands[0].CJ = edge_cj + (edge_cj & 1);
-            ncands = 1;
-        }
         for (int div : {2, 4, 6, 8, 12}) {
-            if (edge_cj > 0) break;
             LaunchShape c = plain;
             c.nwv = 4;
             c.CJ = (width + div - 1) / div;
