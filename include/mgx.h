@@ -173,12 +173,15 @@ int mgx_plan_download(mgx_plan *plan, double *v_host);
  * per-cycle residual norm is always computed on the device, as the reference
  * does; NULL only skips the copy to the host.
  * A caller that stops on a tolerance runs one cycle (or a few) per call.  Such calls cost
- * what one long call costs: once two calls in a row have continued their predecessor (same
- * Ndown >= 1, Nup, omega with Ndown + Nup <= 4, no mgx_plan_commit / set / upload in
- * between), a call's last launch also runs the next call's opening sweeps and restriction
- * (it writes the end-of-cycle iterate, which the caller sees, and the swept one side by side),
- * and the next such call starts from there: one level-0 launch per cycle instead of two.
- * Same bits either way.  A single long call never pays the extra store. */
+ * what one long call costs: a call's last launch may also run the NEXT call's opening sweeps
+ * and restriction, and a next call that continues it (same Ndown >= 1, Nup, omega with
+ * Ndown + Nup <= 4, no mgx_plan_commit / set / upload in between) starts from there: one
+ * level-0 launch per cycle instead of two.  The end-of-cycle iterate is then produced only
+ * when somebody asks for it (mgx_plan_v_dev / get_dev / download: one more launch).  A call
+ * ends that way once two calls in a row have continued their predecessor, and a call of at
+ * most four cycles also when earlier short calls on the same plan were continued that way (the
+ * plan keeps count, so the series on a plan's second right-hand side pays nothing extra; a
+ * caller who stops calling that way pays the unused launch twice at most).  Same bits either way. */
 int mgx_plan_cycles(mgx_plan *plan, int Nv, int Ndown, int Nup, double omega, int pure_jacobi,
                     double *resnorms, double *times);
 

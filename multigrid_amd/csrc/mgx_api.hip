@@ -123,15 +123,23 @@ struct mgx_plan {
     // change of the data in between, starts from there.  The end-of-cycle iterate itself (what
     // mgx_plan_v_dev() names) is then not in memory: it is `lazy`, and materialize() produces
     // it when somebody asks -- one plain up leg from the closing launch's input, which is kept,
-    // into the array `r` that the fused schedule does not use otherwise.  A call ends this way
-    // when the two calls before it were such continuations (or inside mgx_plan_cycles_until):
-    // a single long call never pays for it.
+    // into the array `r` that the fused schedule does not use otherwise.  Ending a call this way
+    // is a bet of one level-0 launch on the next call being a continuation.  It is placed when
+    // the two calls before it were continuations, inside mgx_plan_cycles_until, or when the
+    // call is short (at most HABIT_MAX_CYCLES cycles) and the plan's caller has the `habit`: a
+    // count that goes up (to 3) whenever a carried leg is consumed and down whenever one left by
+    // a short call is dropped unused; the bet is placed from 2 on.  A series of short calls
+    // thus pays three extra launches the first time and none on the later right-hand sides of
+    // the same plan, and a caller who stops calling that way loses two bets at most.
     bool carry_capable = true;  // false for the views full multigrid cycles on
     bool lazy = false;          // v[0] = swept iterate, v[1] = the closing launch's input, result not computed
     bool carry_valid = false;   // (not lazy) v[0] = result, r = swept iterate; lv[1].f its restricted residual
     bool force_carry = false;
     bool last_valid = false;    // the previous call's parameters are below and the data is as it left it
     int last_Ndown = 0, last_Nup = 0, streak = 0;
+    int habit = 0;              // 0..3, see above; lives as long as the plan
+    bool carry_short = false;   // what is carried was left by a short call
+    static constexpr int HABIT_MAX_CYCLES = 4;
     double last_omega = 0;
     unsigned long long carry_key = 0;  // encoded norm after the previous call's last cycle
 };
@@ -331,6 +339,7 @@ int materialize(mgx_plan *p)
 int forget_carry(mgx_plan *p, bool keep_iterate = true)
 {
     int rc = MGX_OK;
+    if ((p->lazy || p->carry_valid) && p->carry_short && p->habit > 0) p->habit--;  // a bet lost
     if (p->lazy && keep_iterate) rc = materialize(p);
     p->lazy = false;
     p->carry_valid = false;
@@ -1059,8 +1068,14 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
         }
         if (Nv > 0) {
             use_carry = cont && (p->lazy || p->carry_valid);
+            if (use_carry) {
+                if (p->habit < 3) p->habit++;
+            } else if ((p->lazy || p->carry_valid) && p->carry_short && p->habit > 0) {
+                p->habit--;  // left behind by a call with other parameters
+            }
             p->streak = cont ? p->streak + 1 : 0;
-            make_carry = can_carry && (p->force_carry || p->streak >= 2);
+            make_carry = can_carry && (p->force_carry || p->streak >= 2 ||
+                                       (p->habit >= 2 && Nv <= mgx_plan::HABIT_MAX_CYCLES));
         }
     }
     if (use_carry) {
@@ -1146,6 +1161,7 @@ int mgx_plan_cycles(mgx_plan *p, int Nv, int Ndown, int Nup, double omega, int p
         p->last_Nup = Nup;
         p->last_omega = omega;
         p->lazy = make_carry;
+        p->carry_short = make_carry && Nv <= mgx_plan::HABIT_MAX_CYCLES;
         if (make_carry)
             HIP_TRY(hipMemcpy(&p->carry_key, p->slots + Nv, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }

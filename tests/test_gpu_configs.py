@@ -351,10 +351,11 @@ def test_32769_host_arrays_against_the_threaded_oracle(mg, O):
 
 
 def test_16385_single_cycle_calls_cost_what_one_long_call_costs(mg):
-    """The benchmark size driven one cycle per call (a caller's own tolerance loop): from the
-    third call on a call's closing launch carries the next call's opening down leg, so 24 calls
-    of one cycle take about as long as one call of 24 (two level-0 launches per cycle would be
-    +70 %), and give the same history and the same solution bits."""
+    """The benchmark size driven one cycle per call (a caller's own tolerance loop): a call's
+    closing launch carries the next call's opening down leg -- from the third call of the first
+    such series on a plan, from the first call of the later ones -- so 24 calls of one cycle take
+    as long as one call of 24 (two level-0 launches per cycle would be +70 %), and give the same
+    history and the same solution bits."""
     import time
     import torch
     from multigrid_amd import rhs
@@ -365,8 +366,8 @@ def test_16385_single_cycle_calls_cost_what_one_long_call_costs(mg):
     zero = mg.colmajor(M, M)
     plan.set(f, zero)
     plan.tune(2, 2, 0.6)
-    for _ in range(4):
-        plan.cycles(1, 2, 2, 0.6)           # the closing launch's own launch shape gets measured here
+    for _ in range(8):
+        plan.cycles(1, 2, 2, 0.6)           # a first series: the plan learns how it is called
     plan.set(f, zero)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -388,4 +389,4 @@ def test_16385_single_cycle_calls_cost_what_one_long_call_costs(mg):
     assert_bits(got, one.ResidualNorms, "ResNorms, 24 calls of one cycle")
     assert all(h[0] == g[-1] for h, g in zip(hist[1:], hist[:-1]))
     assert fp_one == fp_many
-    assert t_many < 1.30 * t_one       # measured x1.08; two level-0 launches per cycle would be x1.7
+    assert t_many < 1.15 * t_one       # measured x1.0; two level-0 launches per cycle would be x1.7
