@@ -1,9 +1,14 @@
-"""Host cost per V(2,2) cycle of the three drivers on a grid small enough that the GPU is
-mostly idle (default 2049^2): the single-device plan, the partitioned plan in C++
-(mgx_mplan_*, R slabs sharing this GPU, one host thread each) and the Python slab driver
-(one rank).  Wall time per cycle of a 200-cycle call next to the device time the same call
-reports; when wall >> device the driver is host-bound.
-   python tools/host_overhead.py [M] [cycles]"""
+"""Host time the slab driver spends per cycle (what bounds a rank when its GPU share is small).
+
+Rank g of R is built with a communicator that moves nothing (tools/rank_share.py), on a grid
+small enough that the device finishes each launch long before the host has enqueued the next
+one: the wall time per cycle is then the host's.  A second figure stubs the launches out
+altogether (Python only).
+
+   python tools/host_overhead.py [--size 4097] [--ranks 8] [--rank 3] [--cycles 200]
+"""
+import argparse
+import json
 import os
 import sys
 import time
@@ -11,44 +16,46 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-import multigrid_amd as mg
-from multigrid_amd import rhs, slab
-
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 2049
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-dx = 1.0 / (M - 1)
+from multigrid_amd import slab
+from rank_share import QuietComm
 
 
-def timed(run):
-    run(5)
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=4097)
+    ap.add_argument("--ranks", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=3)
+    ap.add_argument("--cycles", type=int, default=200)
+    ap.add_argument("--tail-m", type=int, default=257)
+    args = ap.parse_args()
+    M = args.size
+    slab._Comm = lambda group: QuietComm(args.rank, args.ranks)
+    S = slab.SlabSolver(M, 1.0 / (M - 1), 2, tail_m=args.tail_m)
+    S.set_random_rhs()
+    S.tune(2, 2, 0.6)
+    S.cycles(3, 2, 2, 0.6)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = run(K)
+    out = S.cycles(args.cycles, 2, 2, 0.6)
     torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / K
-    return wall * 1e3, out.Times[-1] / K * 1e3
+    wall = (time.perf_counter() - t0) / args.cycles * 1e6
+    dev = float(out.Times[-1]) / args.cycles * 1e6
+    nlaunch = [0]
+    real = S.be.launch
+
+    def stub(op):
+        nlaunch[0] += 1
+
+    S.be.launch = stub
+    t0 = time.perf_counter()
+    S.cycles(args.cycles, 2, 2, 0.6)
+    torch.cuda.synchronize()
+    py = (time.perf_counter() - t0) / args.cycles * 1e6
+    S.be.launch = real
+    print(json.dumps({"M": M, "ranks": args.ranks, "rank": args.rank, "ndist": S.ndist,
+                      "wall_us_per_cycle": wall, "device_us_per_cycle": dev,
+                      "python_only_us_per_cycle": py, "launches_per_cycle": nlaunch[0] / args.cycles}, indent=1))
 
 
-plan = mg.Plan(M, dx, 2)
-plan.set(rhs.random_torch(M), mg.colmajor(M, M))
-w, d = timed(lambda n: plan.cycles(n, 2, 2, 0.6))
-print("M=%d  single-device plan        : wall %.3f ms/cycle, device %.3f ms/cycle" % (M, w, d), flush=True)
-plan.close()
-for R in (1, 2, 4, 8):
-    try:
-        P = mg.MultiPlan(M, dx, 2, nslabs=R, devices=[0] * R, tail_m=max(257, (M - 1) // 8 + 1))
-    except mg.MgxError as e:
-        print("R=%d: %s" % (R, e))
-        continue
-    P.set_random_rhs()
-    w, d = timed(lambda n: P.cycles(n, 2, 2, 0.6))
-    enq = P.stats()[3] / K * 1e3
-    print("M=%d  C++ partitioned plan R=%d  : wall %.3f ms/cycle, device(slab 0) %.3f ms/cycle, host enqueue "
-          "(slab 0's thread) %.3f ms/cycle, tail from %d^2 (on ONE GPU every slab's copy of the tail runs here)"
-          % (M, R, w, d, enq, P.tail_m), flush=True)
-    P.close()
-S = slab.SlabSolver(M, dx, 2, tail_m=max(257, (M - 1) // 8 + 1))
-S.set_random_rhs()
-w, d = timed(lambda n: S.cycles(n, 2, 2, 0.6))
-print("M=%d  Python slab driver, 1 rank : wall %.3f ms/cycle, device %.3f ms/cycle" % (M, w, d), flush=True)
-S.close()
+if __name__ == "__main__":
+    main()
