@@ -172,25 +172,20 @@ __device__ __forceinline__ double jacobi_from_zero(double f, const SweepCoef &c)
     return 0.0 * c.nomega + s;
 }
 
-// interpolated coarse value at fine point (i, j); C holds the coarse level in layout LC
+// Interpolated coarse value at fine point (i, j); C holds the coarse level in layout LC.
+// The four coarse cells around the point lie inside the array whatever the parities (at worst
+// in its border), so all four are read at once and the case is picked by selects instead of
+// four divergent branches with an LDS round trip each: the sums are those of the reference's
+// branches, term by term (main.cpp:234-246).
 __device__ __forceinline__ double prolong_at(const double *__restrict__ C, const Lay &LC, int i, int j)
 {
     const int y = at(LC, i >> 1, j >> 1);
     const bool io = i & 1, jo = j & 1;
-    double p;  // main.cpp:234-246
-    if (!io && !jo) {
-        p = C[y];
-    } else if (!io && jo) {
-        p = 0.5 * (C[y] + C[y + LC.ld]);
-    } else if (io && !jo) {
-        p = 0.5 * (C[y] + C[y + 1]);
-    } else {
-        double s = C[y] + C[y + 1];
-        s = s + C[y + LC.ld];
-        s = s + C[y + LC.ld + 1];
-        p = 0.25 * s;
-    }
-    return p;
+    const double c00 = C[y], c10 = C[y + 1], c01 = C[y + LC.ld], c11 = C[y + LC.ld + 1];
+    const double t1 = c00 + (io ? c10 : c01);  // both half-way cases, and the first sum of the centre case
+    double t3 = t1 + c01;
+    t3 = t3 + c11;
+    return (io && jo) ? 0.25 * t3 : ((io || jo) ? 0.5 * t1 : c00);
 }
 
 // the four neighbours of every point of the thread, requested together so that their LDS
