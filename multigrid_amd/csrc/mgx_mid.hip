@@ -50,6 +50,22 @@
 
 namespace mgx {
 
+// -DMGX_MID_TRACE: thread 0 of the middle workgroup of the launches whose level 0 has
+// g_mid_trace_m rows leaves the time (100 MHz clock) of every step in a device array
+// (row 0: down launch, row 1: up launch); mgx_debug_mid_trace() selects and copies out
+#ifdef MGX_MID_TRACE
+__device__ unsigned long long g_mid_trace[2][64];
+__device__ int g_mid_trace_m;
+#define MT(row, k)                                                                                          \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && (int)blockIdx.x == A.nti / 2 && (int)blockIdx.y == A.ntj / 2 &&             \
+            A.m[0] == g_mid_trace_m)                                                                        \
+            g_mid_trace[row][k] = wall_clock64();                                                           \
+    } while (0)
+#else
+#define MT(row, k) do { } while (0)
+#endif
+
 namespace {
 
 struct Span {
@@ -240,6 +256,7 @@ __global__ __launch_bounds__(1024) void k_mid_down(const MidArgs A)
     extern __shared__ __align__(16) double lds[];
     double *U = lds;
     double *W = lds + A.stride;
+    MT(0, 0);
     Span ni[NL + 1], oi[NL + 1], nj[NL + 1], oj[NL + 1];
     down_spans<NL>(A, (int)blockIdx.x, A.tile_i, A.nti, ni, oi);
     down_spans<NL>(A, (int)blockIdx.y, A.tile_j, A.ntj, nj, oj);
@@ -262,6 +279,7 @@ __global__ __launch_bounds__(1024) void k_mid_down(const MidArgs A)
         const Lay L = lay_of(si, sj);
         const Pts P = pts_of(si, sj, L);
         const SweepCoef c{A.h2[k], A.invh2[k], A.omega, A.nomega};
+        MT(0, 10 * k + 1);
         zero_border(U, W, sj, L);
         // the first sweep from zero needs f at the point only (main.cpp:321)
 #pragma unroll
@@ -272,12 +290,14 @@ __global__ __launch_bounds__(1024) void k_mid_down(const MidArgs A)
             }
         }
         __syncthreads();
+        MT(0, 10 * k + 2);
         for (int s = 1; s < A.ndown; s++) {
             sweep_pts(U, W, P, L, c, f, u, nullptr, L);
             double *t = U;
             U = W;
             W = t;
         }
+        MT(0, 10 * k + 3);
         {  // main.cpp:325: the residual, into the idle array
             Nbr<Q> N;
             read_neighbours(U, P, L, N);
@@ -294,6 +314,7 @@ __global__ __launch_bounds__(1024) void k_mid_down(const MidArgs A)
             }
             __syncthreads();
         }
+        MT(0, 10 * k + 4);
         // main.cpp:327: every thread restricts at ITS points of the next level, whose
         // right-hand side therefore never leaves the registers
         const Span ci = ni[k + 1], cj = nj[k + 1];
@@ -324,6 +345,7 @@ __global__ __launch_bounds__(1024) void k_mid_down(const MidArgs A)
             }
         }
         if (k + 1 < NL) __syncthreads();  // the residual is spent: its array serves the next level
+        MT(0, 10 * k + 5);
     }
 }
 
@@ -334,6 +356,7 @@ __global__ __launch_bounds__(1024) void k_mid_up(const MidArgs A)
     double *C = lds;
     double *U = lds + A.stride;
     double *W = lds + 2 * A.stride;
+    MT(1, 0);
     Span gi[NL], gj[NL], cli, clj, owni, ownj;
     up_spans<NL>(A, (int)blockIdx.x, A.tile_i, A.nti, gi, cli, owni);
     up_spans<NL>(A, (int)blockIdx.y, A.tile_j, A.ntj, gj, clj, ownj);
@@ -373,9 +396,11 @@ __global__ __launch_bounds__(1024) void k_mid_up(const MidArgs A)
             if (P.ok(q)) C[P.x + q * P.xs] = pc[q];
     }
 
+    MT(1, 1);
     double u[Q];
 #pragma unroll
     for (int k = NL - 1; k >= 0; k--) {
+        MT(1, 10 * k + 2);
         const Span si = gi[k], sj = gj[k];
         const Lay L = lay_of(si, sj);
         const Pts P = pts_of(si, sj, L);
@@ -393,12 +418,14 @@ __global__ __launch_bounds__(1024) void k_mid_up(const MidArgs A)
             }
         }
         __syncthreads();
+        MT(1, 10 * k + 3);
         for (int s = 2; s <= A.ndown; s++) {
             sweep_pts(U, W, P, L, c, pf[k], u, s == A.ndown ? C : nullptr, LC);
             double *t = U;
             U = W;
             W = t;
         }
+        MT(1, 10 * k + 4);
         for (int s = 0; s < A.nup; s++) {  // main.cpp:343
             sweep_pts(U, W, P, L, c, pf[k], u, nullptr, LC);
             double *t = U;
@@ -406,6 +433,7 @@ __global__ __launch_bounds__(1024) void k_mid_up(const MidArgs A)
             W = t;
         }
         // this level's iterate is the next one's coarse level; the spent coarse array joins the pair
+        MT(1, 10 * k + 5);
         double *t = C;
         C = U;
         U = t;
@@ -419,6 +447,7 @@ __global__ __launch_bounds__(1024) void k_mid_up(const MidArgs A)
                 if (P.ok(q) && P.i >= owni.lo && P.i <= owni.hi && j >= ownj.lo && j <= ownj.hi)
                     g[(size_t)P.i + (size_t)j * m0] = u[q];
             }
+            MT(1, 60);
         }
     }
 }
@@ -797,6 +826,21 @@ void spans_out(bool down, const mgx::MidArgs &A, int tile, int t, int *lo, int *
 }
 
 } // namespace
+
+#ifdef MGX_MID_TRACE
+// m >= 0: trace the launches whose level 0 has m rows from now on; out: the 2 x 64 marks so far
+extern "C" int mgx_debug_mid_trace(int m, unsigned long long *out)
+{
+    hipError_t e = hipSuccess;
+    if (m >= 0) {
+        static const unsigned long long zeros[2 * 64] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(mgx::g_mid_trace), zeros, sizeof(zeros));
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(mgx::g_mid_trace_m), &m, sizeof(int));
+    }
+    if (e == hipSuccess && out) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx::g_mid_trace), sizeof(unsigned long long) * 2 * 64);
+    return (int)e;
+}
+#endif
 
 extern "C" {
 

@@ -109,3 +109,21 @@ def test_non_finite_right_hand_side(mg, O, monkeypatch):
     assert np.array_equal(np.isnan(sol), np.isnan(ref_sol))
     ok = ~np.isnan(ref_sol)
     assert np.array_equal(sol[ok].view(np.uint64), ref_sol[ok].view(np.uint64))
+
+
+@pytest.mark.parametrize("threads", [64, 256, 1024])
+def test_tail_workgroup_sizes_give_the_same_bits(threads):
+    """The one-workgroup tail has an instance for levels that one pass of the workgroup covers
+    (the default 1024 threads and a top level of at most 33 x 33), one whose top level takes
+    several passes, and a general one (fewer threads, MGX_TAIL_THREADS): all three must give
+    the oracle's bits.  The thread count is read once per process, hence the child process
+    (a short run of the randomised parity sweep over the schedules that use the tail)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGX_TAIL_THREADS=str(threads), FUZZ_LEAN="1", FUZZ_CASES="150", FUZZ_MODES="2,6,7,8,9")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "60", str(threads), "600"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "bit-identical to the oracle" in out.stdout
