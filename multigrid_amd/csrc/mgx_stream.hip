@@ -527,11 +527,29 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
     }
 }
 
+// -DMGX_STREAM_TRACE: every wave of a four-sweep up+down launch of TWO column ranges (the edge
+// bands of a slab in a V(2,2) cycle) leaves its start and end time (100 MHz clock) and where it ran; mgx_debug_stream_trace()
+// copies the marks out (tools/trace_edge_launch.py)
+#ifdef MGX_STREAM_TRACE
+constexpr int STREAM_TRACE_WAVES = 16384;
+__device__ unsigned long long g_stream_trace[4 * STREAM_TRACE_WAVES];
+#endif
+
 template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
 __global__ __launch_bounds__(512) void k_stream(const StreamArgs A)
 {
     using G = Geo<NS, PA, NM, RES>;
     int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+#ifdef MGX_STREAM_TRACE
+    const int trace_id = ((int)blockIdx.x + (int)blockIdx.y * (int)gridDim.x) * A.nwv + (int)(threadIdx.x >> 6);
+    const bool traced = NS == 4 && RES == 1 && A.jhi2 > A.jlo2 && (threadIdx.x & 63) == 0 && trace_id < STREAM_TRACE_WAVES;
+    if (traced) {
+        g_stream_trace[4 * trace_id + 0] = wall_clock64();
+        g_stream_trace[4 * trace_id + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                           ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        g_stream_trace[4 * trace_id + 3] = 0;
+    }
+#endif
     if (A.remap) {
         // Workgroups are dealt to the 8 XCDs round-robin by linear id; they are renumbered so
         // that one XCD (one L2) gets a contiguous run of the (strip group, chunk) plane, with
@@ -566,6 +584,13 @@ __global__ __launch_bounds__(512) void k_stream(const StreamArgs A)
         stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, false, true>(A, strip, by);
     else
         stream_wave<NS, PA, NM, RES, ZERO_IN, STORE, false, false>(A, strip, by);
+#ifdef MGX_STREAM_TRACE
+    if (traced) {
+        g_stream_trace[4 * trace_id + 1] = wall_clock64();
+        g_stream_trace[4 * trace_id + 3] = 1 + (edge ? 1 : 0) + (cf ? 2 : 0) + ((unsigned long long)(jb - ja) << 8) +
+                                           ((unsigned long long)strip << 16) + ((unsigned long long)by << 32);
+    }
+#endif
 }
 
 int env_int(const char *name, int dflt)
@@ -838,6 +863,23 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
         // chunks march longer: measured (two, four and eight strips per workgroup give the same 40 us
         // at their best chunk length: four it is).
         const int width = std::max(A.jhi - A.jlo, A.jhi2 - A.jlo2);
+        // Such a launch is bound by instruction issue, not by memory: a wave alone on its SIMD
+        // marches a column in 0.7 us whatever the depth of its load queue, and two waves on one
+        // SIMD take turns (one finishes as if alone, the other up to twice as late).  With more
+        // workgroups than CUs the launch therefore lasts as long as two of them in a row: the
+        // candidate that comes first leaves every CU at most one (16385 rows, two bands of 88
+        // columns: three chunks of 30 per band instead of six of 16).
+        {
+            const long nsg4 = (A.nstrips + 3) / 4;
+            const long per_range = cu_count() / nsg4 / nranges;
+            if (per_range >= 1) {
+                LaunchShape c = plain;
+                c.nwv = 4;
+                c.CJ = (int)((width + per_range - 1) / per_range);
+                c.CJ += c.CJ & 1;
+                if (c.CJ >= 6) add(c);
+            }
+        }
         for (int div : {2, 4, 6, 8, 12}) {
             LaunchShape c = plain;
             c.nwv = 4;
@@ -1021,3 +1063,17 @@ hipError_t launch_stream(const StreamOp &op, const StreamArgs &A, hipStream_t s)
 }
 
 } // namespace mgx
+
+#ifdef MGX_STREAM_TRACE
+// clear != 0: forget the marks; out: 4 x STREAM_TRACE_WAVES values (start, end, where, what) or NULL
+extern "C" int mgx_debug_stream_trace(int clear, unsigned long long *out)
+{
+    hipError_t e = hipSuccess;
+    void *p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(mgx::g_stream_trace));
+    if (e == hipSuccess && clear) e = hipMemset(p, 0, sizeof(unsigned long long) * 4 * mgx::STREAM_TRACE_WAVES);
+    if (e == hipSuccess && out)
+        e = hipMemcpy(out, p, sizeof(unsigned long long) * 4 * mgx::STREAM_TRACE_WAVES, hipMemcpyDeviceToHost);
+    return (int)e;
+}
+#endif
