@@ -804,14 +804,14 @@ hipError_t launch_shape(StreamArgs A, const LaunchShape &sh, hipStream_t s)
 // all resident from the start, chunks as long as that allows.  For a tall slab of a partitioned
 // level (16385 rows x 2048 columns: 18 groups of eight strips x 14 chunks of 146 columns) the
 // shapes above leave chunks of 64-90 columns, of which the 11 halo columns are a sixth.
-bool one_round_shape(int nstrips, int ncolsout, int nwv, int per_cu, LaunchShape &sh)
+bool one_round_shape(int nstrips, int ncolsout, int nwv, int per_cu, LaunchShape &sh, int min_cj = 48)
 {
     const long nsg = (nstrips + nwv - 1) / nwv;
     const long nch = (long)per_cu * cu_count() / nsg;
     if (nch < 1) return false;
     int cj = (int)((ncolsout + nch - 1) / nch);
     cj += cj & 1;
-    if (cj < 48) return false;
+    if (cj < min_cj) return false;
     sh.nwv = nwv;
     sh.CJ = cj;
     sh.lds = 0;
@@ -886,6 +886,17 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
             c.CJ = (width + div - 1) / div;
             c.CJ += c.CJ & 1;
             if (c.CJ >= 6) add(c);
+        }
+    }
+    if (ZERO_IN && nranges == 1 && (long)m * ncolsout >= (1L << 18) && (long)m * ncolsout <= (32L << 20)) {
+        // A level of 0.25-32 M points whose iterate starts from zero (levels 2-3 of a big
+        // problem, the slabs of levels 1-3 of a partitioned one): bound by instruction issue
+        // like the narrow band above, and the plain rule's short chunks (14 columns at 2049^2)
+        // march two thirds as many halo columns again.  One, two or three workgroups on every
+        // CU, chunks as long as that allows.
+        for (int per_cu : {1, 2, 3}) {
+            LaunchShape r = plain;
+            if (one_round_shape(A.nstrips, ncolsout, 4, per_cu, r, 8)) add(r);
         }
     }
     static const int tune = env_int("MGX_TUNE", 1);
