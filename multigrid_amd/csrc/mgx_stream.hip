@@ -533,6 +533,7 @@ __device__ __forceinline__ void stream_wave(const StreamArgs &A, const int strip
 #ifdef MGX_STREAM_TRACE
 constexpr int STREAM_TRACE_WAVES = 16384;
 __device__ unsigned long long g_stream_trace[4 * STREAM_TRACE_WAVES];
+__device__ int g_stream_trace_ranges = 2;  // which launches: those of this many column ranges
 #endif
 
 template <int NS, int PA, int NM, int RES, bool ZERO_IN, bool STORE>
@@ -542,7 +543,8 @@ __global__ __launch_bounds__(512) void k_stream(const StreamArgs A)
     int bx = (int)blockIdx.x, by = (int)blockIdx.y;
 #ifdef MGX_STREAM_TRACE
     const int trace_id = ((int)blockIdx.x + (int)blockIdx.y * (int)gridDim.x) * A.nwv + (int)(threadIdx.x >> 6);
-    const bool traced = NS == 4 && RES == 1 && A.jhi2 > A.jlo2 && (threadIdx.x & 63) == 0 && trace_id < STREAM_TRACE_WAVES;
+    const bool traced = NS == 4 && RES == 1 && !ZERO_IN && (A.jhi2 > A.jlo2 ? 2 : 1) == g_stream_trace_ranges &&
+                        (threadIdx.x & 63) == 0 && trace_id < STREAM_TRACE_WAVES;
     if (traced) {
         g_stream_trace[4 * trace_id + 0] = wall_clock64();
         g_stream_trace[4 * trace_id + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
@@ -1076,13 +1078,15 @@ hipError_t launch_stream(const StreamOp &op, const StreamArgs &A, hipStream_t s)
 } // namespace mgx
 
 #ifdef MGX_STREAM_TRACE
-// clear != 0: forget the marks; out: 4 x STREAM_TRACE_WAVES values (start, end, where, what) or NULL
-extern "C" int mgx_debug_stream_trace(int clear, unsigned long long *out)
+// ranges > 0: forget the marks and trace the launches of that many column ranges from now on;
+// out: 4 x STREAM_TRACE_WAVES values (start, end, where, what) or NULL
+extern "C" int mgx_debug_stream_trace(int ranges, unsigned long long *out)
 {
     hipError_t e = hipSuccess;
     void *p = nullptr;
     e = hipGetSymbolAddress(&p, HIP_SYMBOL(mgx::g_stream_trace));
-    if (e == hipSuccess && clear) e = hipMemset(p, 0, sizeof(unsigned long long) * 4 * mgx::STREAM_TRACE_WAVES);
+    if (e == hipSuccess && ranges > 0) e = hipMemset(p, 0, sizeof(unsigned long long) * 4 * mgx::STREAM_TRACE_WAVES);
+    if (e == hipSuccess && ranges > 0) e = hipMemcpyToSymbol(HIP_SYMBOL(mgx::g_stream_trace_ranges), &ranges, sizeof(int));
     if (e == hipSuccess && out)
         e = hipMemcpy(out, p, sizeof(unsigned long long) * 4 * mgx::STREAM_TRACE_WAVES, hipMemcpyDeviceToHost);
     return (int)e;

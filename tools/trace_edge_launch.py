@@ -24,17 +24,25 @@ def main():
     ap.add_argument("--size", type=int, default=16385)
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--rank", type=int, default=3)
+    ap.add_argument("--interior", action="store_true", help="the one-range launch (a slab's interior columns; with "
+                                                            "--ranks 1 the whole grid) instead of the edge bands")
     args = ap.parse_args()
     L = _lib.load()
     L.mgx_debug_stream_trace.argtypes = [ctypes.c_int, ctypes.c_void_p]
     M = args.size
-    slab._Comm = lambda group: QuietComm(args.rank, args.ranks)
-    S = slab.SlabSolver(M, 1.0 / (M - 1), 2)
-    S.set_random_rhs()
+    if args.ranks > 1:
+        slab._Comm = lambda group: QuietComm(args.rank, args.ranks)
+        S = slab.SlabSolver(M, 1.0 / (M - 1), 2)
+        S.set_random_rhs()
+    else:
+        import multigrid_amd as mg
+        from multigrid_amd import rhs
+        S = mg.Plan(M, 1.0 / (M - 1), 2)
+        S.set(rhs.random_torch(M), mg.colmajor(M, M))
     S.tune(2, 2, 0.6)
     S.cycles(3, 2, 2, 0.6)
     torch.cuda.synchronize()
-    L.mgx_debug_stream_trace(1, None)
+    L.mgx_debug_stream_trace(1 if args.interior else 2, None)
     S.cycles(3, 2, 2, 0.6)
     torch.cuda.synchronize()
     n = 16384
@@ -53,7 +61,7 @@ def main():
     simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
     where = xcc * 100000 + se * 10000 + sh * 1000 + cu * 10 + simd
     kinds = t[:, 3] & 0xff
-    width = (t[:, 3] >> 8) & 0xff
+    width = (t[:, 3] >> 8) & 0xff          # modulo 256: the interior's chunks are longer
     strip, chunk = (t[:, 3] >> 16) & 0xffff, (t[:, 3] >> 32) & 0xffff
     print("waves %d, launch spans %.1f us (first start to last end)" % (len(t), en.max()))
     pct = lambda a: "min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f" % (a.min(), np.percentile(a, 10), np.median(a),
