@@ -890,12 +890,14 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
             if (c.CJ >= 6) add(c);
         }
     }
-    if (ZERO_IN && nranges == 1 && (long)m * ncolsout >= (1L << 18) && (long)m * ncolsout <= (32L << 20)) {
-        // A level of 0.25-32 M points whose iterate starts from zero (levels 2-3 of a big
-        // problem, the slabs of levels 1-3 of a partitioned one): bound by instruction issue
-        // like the narrow band above, and the plain rule's short chunks (14 columns at 2049^2)
-        // march two thirds as many halo columns again.  One, two or three workgroups on every
-        // CU, chunks as long as that allows.
+    if (ZERO_IN && nranges == 1 && (long)m * ncolsout >= (1L << 18) && (long)m * ncolsout <= (12L << 20)) {
+        // A level of 0.25-12 M points whose iterate starts from zero (level 3 of a big problem,
+        // the slabs of levels 1-3 of a partitioned one): the plain rule's short chunks (14
+        // columns at 2049^2) march two thirds as many halo columns again.  One, two or three
+        // workgroups on every CU, chunks as long as that allows: 2049^2 legs 22.7 + 15.4 ->
+        // 21.3 + 14.5 us.  (Not for bigger launches: a 4097^2 level repeated for the
+        // measurement stays in the memory-side cache and the winner of that contest, 50-column
+        // chunks, then runs 62 us inside a cycle against the plain rule's 60.8.)
         for (int per_cu : {1, 2, 3}) {
             LaunchShape r = plain;
             if (one_round_shape(A.nstrips, ncolsout, 4, per_cu, r, 8)) add(r);
