@@ -49,10 +49,11 @@ struct LevelView {
 // every level of at most 33x33 points is covered in ONE pass -- a thread has one point of the
 // level or none -- and that is the case the phases are written for: each of them is a chain
 // of dependent instructions of a single wave (index arithmetic, LDS round trip, eight
-// dependent fp64 operations, barrier), about 0.3-0.4 us whatever the size of the level, so
-// what a phase costs is the number of instructions on that chain.  A thread's point of a
-// level is therefore worked out once per level (Pt), not once per phase, and the loops over
-// further passes exist only where a level needs them.
+// dependent fp64 operations, barrier) and takes as long for a 5x5 level as for a 33x33 one:
+// what a phase costs is the number of instructions on that chain (0.16-0.3 us as written
+// here; 0.3-0.45 us with a loop nest over a thread's points in every phase).  A thread's
+// point of a level is therefore worked out once per level (Pt), not once per phase, and the
+// loops over further passes exist only where a level needs them.
 __device__ __forceinline__ int tail_lanes_log2(int m) { return m - 2 <= 16 ? 4 : (m - 2 <= 32 ? 5 : 6); }
 
 struct Pt {
