@@ -921,13 +921,13 @@ hipError_t launch_one(StreamArgs A, hipStream_t s)
     if (tune_now_flag()) {
         // Decide at once: a launch reads uin/f/cin and writes uout/cout (never its own input)
         // and merges the norm by a max, so repeating it leaves the same result.  Every
-        // candidate runs once untimed and WINDOW times between one event pair, twice.
+        // candidate runs once untimed and WINDOW times between one event pair, three times.
         hipError_t rc = hipSuccess;
         bool ok = true;
-        // two interleaved passes over the candidates, the smaller time of each counts: a
+        // three interleaved passes over the candidates, the smallest time of each counts: a
         // disturbance during one window (another tenant of the node, a clock ramp) must not
         // decide between shapes that differ by 2 %
-        for (int pass = 0; pass < 2 && ok; pass++)
+        for (int pass = 0; pass < 3 && ok; pass++)
             for (int k = 0; k < e.ncand && ok; k++) {
                 rc = launch_shape<NS, PA, NM, RES, ZERO_IN, STORE>(A, e.cand[k], s);
                 ok = rc == hipSuccess && hipEventRecord(e.e0[0], s) == hipSuccess;
