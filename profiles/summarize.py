@@ -49,7 +49,7 @@ def main(path):
                                                                               sum(fine) / len(fine) / 1e3, med / 1e3,
                                                                               min(fine) / 1e3, max(fine) / 1e3, vg, sg,
                                                                               lds, scr))
-    print("(calls = launches of the shape the timed region uses, incl. the three per pass mgx_plan_tune runs of it; "
+    print("(calls = launches of the shape the timed region uses, incl. the launches of it that mgx_plan_tune times; "
           "all = every launch of the kernel, every level and trial shape)")
     print("(*vgpr: the trace's encoding of the allocation, not the register count; the ISA of the level-0 up+down "
           "instance uses 149 vector registers, two waves per SIMD)")
