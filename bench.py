@@ -297,6 +297,8 @@ def main():
         # launcher.  It touches neither torch nor the GPU; the ranks are its children.
         sys.exit(launch_ranks(args.gpus, real_stdout))
 
+    # the HIP runtime reads this when it comes up (dmabuf IPC, what RCCL between processes needs here)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -313,7 +315,6 @@ def main():
     torch.cuda.set_device(dev)
     grouped = world > 1 or (os.environ.get("MGX_COMM_FORCE") == "1" and "MASTER_ADDR" in os.environ)
     if grouped:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
